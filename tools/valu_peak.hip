@@ -1,0 +1,96 @@
+// FP32 VALU issue-rate microbenchmark for MI355X (gfx950).
+// Register-only chains of the instruction forms the sphere scan can be built from, at 1..8
+// waves per SIMD. Reports, per form: wall TFLOP/s, shader cycles per wave-instruction per SIMD
+// (from s_memtime, so independent of the clock the chip holds) and the effective clock.
+// Answers SURVEY.md 7.3 item 2: which form reaches the 157.3 TFLOP/s "FP32 vector" figure.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/build/valu_peak tools/valu_peak.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int ITERS = 1 << 16;
+constexpr int ILP = 16;
+
+#define KERNEL_HEAD(name)                                                                     \
+    __global__ void __launch_bounds__(256) name(float* out, unsigned long long* cyc, float a, float b) { \
+        float acc[ILP];                                                                       \
+        _Pragma("unroll") for (int i = 0; i < ILP; ++i) acc[i] = threadIdx.x * 0.001f + i;    \
+        float2v acc2[ILP];                                                                    \
+        _Pragma("unroll") for (int i = 0; i < ILP; ++i) acc2[i] = float2v{acc[i], -acc[i]};   \
+        float2v va = {a, a * 1.0001f}, vb = {b, b * 0.999f};                                  \
+        (void)va; (void)vb;                                                                   \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                 \
+        for (int it = 0; it < ITERS; ++it) {                                                  \
+            _Pragma("unroll") for (int i = 0; i < ILP; ++i) {
+
+#define KERNEL_TAIL                                                                           \
+            }                                                                                 \
+        }                                                                                     \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                 \
+        float s = 0.f;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < ILP; ++i) s += acc[i] + acc2[i].x + acc2[i].y;  \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                       \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;      \
+    }
+
+KERNEL_HEAD(k_fma_vvv)   asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));   KERNEL_TAIL
+KERNEL_HEAD(k_fma_svv)   asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(acc[i]) : "s"(a), "v"(b));   KERNEL_TAIL
+KERNEL_HEAD(k_fmac_sv)   asm volatile("v_fmac_f32 %0, %1, %2"    : "+v"(acc[i]) : "s"(a), "v"(b));   KERNEL_TAIL
+KERNEL_HEAD(k_fmac_vv)   asm volatile("v_fmac_f32 %0, %1, %2"    : "+v"(acc[i]) : "v"(a), "v"(b));   KERNEL_TAIL
+KERNEL_HEAD(k_mul_sv)    asm volatile("v_mul_f32 %0, %1, %0"     : "+v"(acc[i]) : "s"(a));           KERNEL_TAIL
+KERNEL_HEAD(k_sub_sv)    asm volatile("v_sub_f32 %0, %1, %0"     : "+v"(acc[i]) : "s"(a));           KERNEL_TAIL
+KERNEL_HEAD(k_cmp_sv)    asm volatile("v_cmp_gt_f32 vcc, %1, %0" : "+v"(acc[i]) : "s"(a) : "vcc");   KERNEL_TAIL
+KERNEL_HEAD(k_pk_vvv)    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc2[i]) : "v"(va), "v"(vb)); KERNEL_TAIL
+KERNEL_HEAD(k_pk_svv)    asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc2[i]) : "s"(va), "v"(vb)); KERNEL_TAIL
+KERNEL_HEAD(k_pk_mul_sv) asm volatile("v_pk_mul_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
+KERNEL_HEAD(k_pk_add_sv) asm volatile("v_pk_add_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
+
+typedef void (*kern_t)(float*, unsigned long long*, float, float);
+struct Form { const char* name; kern_t k; int flops_per_lane; };
+
+int main() {
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    int cus = p.multiProcessorCount;
+    printf("device %s  CUs %d  max clock %.0f MHz\n", p.gcnArchName, cus, p.clockRate / 1000.0);
+    float* out; CK(hipMalloc(&out, sizeof(float) * 256 * cus * 8));
+    unsigned long long* cyc; CK(hipMalloc(&cyc, sizeof(unsigned long long) * cus * 8 * 4));
+    std::vector<unsigned long long> hc(cus * 8 * 4);
+    Form forms[] = {
+        {"v_fma_f32 v,v,v", k_fma_vvv, 2}, {"v_fma_f32 s,v,v", k_fma_svv, 2}, {"v_fmac_f32 s,v", k_fmac_sv, 2},
+        {"v_fmac_f32 v,v", k_fmac_vv, 2}, {"v_mul_f32 s,v", k_mul_sv, 1}, {"v_sub_f32 s,v", k_sub_sv, 1},
+        {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4},
+        {"v_pk_mul_f32 s,v", k_pk_mul_sv, 2}, {"v_pk_add_f32 s,v", k_pk_add_sv, 2},
+    };
+    printf("%-20s %-6s %-9s %-9s %-14s %-9s\n", "form", "w/SIMD", "ms", "TFLOP/s", "cyc/inst/SIMD", "clock GHz");
+    for (const Form& f : forms) {
+        for (int k = 1; k <= 8; k *= 2) {           // k blocks of 256 threads per CU = k waves per SIMD
+            int grid = cus * k;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(f.k, dim3(grid), dim3(256), 0, 0, out, cyc, 0.999f, 0.001f);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(f.k, dim3(grid), dim3(256), 0, 0, out, cyc, 0.999f, 0.001f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(hc.data(), cyc, sizeof(unsigned long long) * grid * 4, hipMemcpyDeviceToHost));
+            std::sort(hc.begin(), hc.begin() + grid * 4);
+            double med_cyc = double(hc[grid * 2]);
+            double inst = double(ITERS) * ILP;                  // per wave
+            double cyc_per_inst_simd = med_cyc / (inst * k);    // k waves share a SIMD
+            double flops = double(grid) * 256 * inst * f.flops_per_lane;
+            printf("%-20s %-6d %-9.3f %-9.2f %-14.3f %-9.3f\n", f.name, k, ms, flops / ms / 1e9, cyc_per_inst_simd,
+                   med_cyc / (ms * 1e6));
+            CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+        }
+    }
+    CK(hipFree(out)); CK(hipFree(cyc));
+    return 0;
+}
