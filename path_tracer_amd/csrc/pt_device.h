@@ -1,0 +1,265 @@
+// pt_device.h — device functions of the sample loop for gfx950 (MI355X, CDNA4).
+//
+// One lane owns one path. A ray is (origin o, UNIT direction dh, len) with the reference's
+// un-normalised direction d = len * dh, because the reference measures t in units of |d|
+// (Sphere.cpp:7-17, t_min = 0.001 at Path Tracer.cpp:92) and reads |d| in the dielectric
+// cosine (Dielectric.cpp:19). PhysicsVector<3> becomes three fp32 registers.
+//
+// The closest-hit search (HittableList.cpp:21-36 over Sphere.cpp:5-23) is split in three:
+//   tier 1  every sphere, packed fp32 FMA on sphere PAIRS held in scalar registers:
+//           T = ((c-o).dh)^2 - |c-o|^2 + r^2, written so that the sphere data only multiplies
+//           per-ray constants:  b = c.dh - o.dh,  T = b*b + 2 o.c - |o|^2 - K,  K = |c|^2 - r^2;
+//           T >= 0  <=>  the ray's line meets the sphere (disc >= 0 at Sphere.cpp:10-13);
+//   tier 2  only for the spheres some lane flagged: roots b -+ sqrt(T), the reference's root
+//           choice and range test (Sphere.cpp:16-23), closest-so-far update with ties to the
+//           later index (HittableList.cpp:28-31);
+//   finish  once per ray, for the winning sphere only, in fp64 from the double-precision scene:
+//           t, point, outward normal, front face (Sphere.cpp:26-30, Hittable.h:26-31).
+// The sphere the ray starts on (`prev`) is left out of tier 2 and handled in closed form: its
+// near root is the start point itself, its far root is 2b.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_DEV __device__ __forceinline__
+
+namespace ptd {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct f3 { float x, y, z; };
+PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }   // VectorFunc.cpp:22-28
+PT_DEV float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+PT_DEV f3 fma3(f3 a, float s, f3 c) {   // a*s + c
+    return mk3(__builtin_fmaf(a.x, s, c.x), __builtin_fmaf(a.y, s, c.y), __builtin_fmaf(a.z, s, c.z));
+}
+PT_DEV f3 select3(bool c, f3 a, f3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+
+// ---------------------------------------------------------------------------------------------
+// Scene and camera as the kernels see them.
+// ---------------------------------------------------------------------------------------------
+struct GeomRec {          // double-precision sphere for the finish (Sphere.h:20-21)
+    double cx, cy, cz, r, inv_r, r2;
+};
+struct MatRec {           // 32 bytes, two float4 loads
+    float ar, ag, ab, fuzz;        // Lambertian.h:18, Metal.h:17-18
+    float ior, inv_ior, r0;        // Dielectric.h:21; r0 = ((1-ior)/(1+ior))^2, Dielectric.cpp:47-48
+    int kind;
+};
+struct SceneDev {
+    const float* scan;     // n_pad/2 pair records of 8 floats: cx0,cx1, cy0,cy1, cz0,cz1, K0,K1
+    const GeomRec* geom;   // n
+    const MatRec* mat;     // n
+    int n;                 // spheres in list order
+    int n_pad;             // multiple of 4; the padding never hits
+};
+struct CameraDev {         // Camera.cpp:27-31, as floats; ll_rel = lowerLeft - position
+    f3 pos, ll_rel, hor, ver, u, v;
+    float lens;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Random numbers: philox4x32-10, one block per (pixel, sample, bounce). Replaces RNG-A
+// (Path Tracer.cpp:48-52), RNG-B (VectorFunc.cpp:15-19) and RNG-C (Dielectric.cpp:52-56).
+// ---------------------------------------------------------------------------------------------
+struct u4 { uint32_t x, y, z, w; };
+PT_DEV u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = uint64_t(0xD2511F53u) * c0;
+        uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
+        uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c1 = uint32_t(p1);
+        c3 = uint32_t(p0);
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    u4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+PT_DEV float u24(uint32_t w) { return float(w >> 8) * (1.0f / 16777216.0f); }   // exact, in [0, 1)
+
+// sin / cos of 2*pi*x on the hardware unit (v_sin_f32 / v_cos_f32 take revolutions).
+PT_DEV float sin_rev(float x) { return __builtin_amdgcn_sinf(x); }
+PT_DEV float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }
+PT_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// VectorFunc.cpp:37-43: theta = 2 pi u1, phi = acos(1 - 2 u2), (sin phi cos theta, sin phi sin theta,
+// cos phi). sin(acos z) = sqrt(1 - z^2), so no acos is needed.
+PT_DEV f3 sphere_point(float u1, float u2) {
+    float z = __builtin_fmaf(-2.0f, u2, 1.0f);
+    float s = fast_sqrt(__builtin_fmaxf(__builtin_fmaf(-z, z, 1.0f), 0.0f));
+    return mk3(s * cos_rev(u1), s * sin_rev(u1), z);
+}
+
+// Path Tracer.cpp:270-271 and Camera.cpp:38-46, jitter and unit-disk point given.
+PT_DEV void gen_ray(const CameraDev& cam, int i, int j, float inv_w1, float inv_h1, float u1, float u2, float diskx,
+                    float disky, f3& o, f3& d) {
+    float s = (float(i) + u1) * inv_w1;
+    float t = (float(j) + u2) * inv_h1;
+    float rx = diskx * cam.lens, ry = disky * cam.lens;            // Camera.cpp:40
+    f3 off = fma3(cam.u, rx, cam.v * ry);                          // :42
+    o = cam.pos + off;                                             // :45
+    d = fma3(cam.hor, s, fma3(cam.ver, t, cam.ll_rel)) - off;      // :45
+}
+
+// Path Tracer.cpp:105-107 from the unit direction's y.
+PT_DEV f3 sky(float dy) {
+    float t = 0.5f * (dy + 1.0f);
+    float w = 1.0f - t;
+    return mk3(__builtin_fmaf(0.5f, t, w), __builtin_fmaf(0.7f, t, w), w + t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tier 2 for one flagged sphere: Sphere.cpp:16-23 and HittableList.cpp:28-31 in unit-direction t.
+// ---------------------------------------------------------------------------------------------
+PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, int& best_i) {
+    float s = fast_sqrt(__builtin_fmaxf(T, 0.0f));
+    float t1 = b - s, t2 = b + s;
+    float t = (t1 >= tmin) ? t1 : t2;                              // Sphere.cpp:17-19
+    bool ok = (T >= 0.0f) & (j != prev) & (t >= tmin) & (t <= best_t);   // :13, :20; <= : later index wins ties
+    best_t = ok ? t : best_t;
+    best_i = ok ? j : best_i;
+}
+
+// The linear scan. o, dh: ray origin and unit direction; tmin in unit-direction units
+// (0.001 * len); prev: sphere the ray starts on, or -1. Returns the approximate t and the index
+// of the closest hit (-1: miss).
+PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, float& best_t, int& best_i) {
+    const float nod = -dot(o, dh);
+    const float noo = -dot(o, o);
+    const f3 o2 = o * 2.0f;
+    best_t = __builtin_inff();
+    best_i = -1;
+    const v2f* __restrict__ S = reinterpret_cast<const v2f*>(sc.scan);
+    const int npairs = sc.n_pad >> 1;
+    for (int q = 0; q < npairs; q += 2) {
+        v2f B[2], T[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v2f cx = S[4 * (q + h) + 0], cy = S[4 * (q + h) + 1], cz = S[4 * (q + h) + 2], K = S[4 * (q + h) + 3];
+            v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{nod, nod});
+            b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
+            b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
+            v2f e = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, v2f{noo, noo});
+            e = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, e);
+            e = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, e);
+            e = e - K;
+            B[h] = b;
+            T[h] = __builtin_elementwise_fma(b, b, e);
+        }
+        float m = __builtin_fmaxf(__builtin_fmaxf(T[0].x, T[0].y), __builtin_fmaxf(T[1].x, T[1].y));
+        if (m >= 0.0f) {
+            const int j = 2 * q;
+            tier2(T[0].x, B[0].x, j + 0, prev, tmin, best_t, best_i);
+            tier2(T[0].y, B[0].y, j + 1, prev, tmin, best_t, best_i);
+            tier2(T[1].x, B[1].x, j + 2, prev, tmin, best_t, best_i);
+            tier2(T[1].y, B[1].y, j + 3, prev, tmin, best_t, best_i);
+        }
+    }
+    // The sphere the ray starts on: the near root is the start point (rejected by t_min in the
+    // reference), the far root is 2b and counts only when the ray heads into the sphere.
+    if (prev >= 0) {
+        const float* rec = sc.scan + 8 * (prev >> 1) + (prev & 1);
+        f3 c = mk3(rec[0], rec[2], rec[4]);
+        float t = 2.0f * dot(c - o, dh);
+        bool ok = (t >= tmin) & (t <= best_t);
+        best_t = ok ? t : best_t;
+        best_i = ok ? prev : best_i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finish: the hit record of the winning sphere in fp64 (Sphere.cpp:6-30, Hittable.h:26-31).
+// t is returned in unit-direction units; the reference's t is t / len.
+// ---------------------------------------------------------------------------------------------
+struct HitRec {
+    f3 p, n;
+    bool front;
+    double t_unit;
+    double px, py, pz, nx, ny, nz;   // the same point and normal before rounding to fp32
+};
+PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, float len) {
+    const GeomRec g = sc.geom[idx];
+    const double ox = o.x, oy = o.y, oz = o.z, dx = dh.x, dy = dh.y, dz = dh.z;
+    const double ocx = ox - g.cx, ocy = oy - g.cy, ocz = oz - g.cz;            // Sphere.cpp:6
+    const double a = dx * dx + dy * dy + dz * dz;                                // :7 (1 +- 2e-7)
+    const double hb = ocx * dx + ocy * dy + ocz * dz;                            // :8
+    const double cc = ocx * ocx + ocy * ocy + ocz * ocz - g.r2;                  // :9
+    double disc = hb * hb - a * cc;                                              // :10
+    disc = disc < 0.0 ? 0.0 : disc;      // tier 2 said "hit" in fp32; a grazing miss becomes a tangent hit
+    const double sq = __builtin_sqrt(disc);                                      // :16
+    const double inv_a = 2.0 - a;        // 1/a to 4e-14 since |a - 1| <= 2e-7
+    const double t1 = (-hb - sq) * inv_a;                                        // :17
+    const double t2 = (-hb + sq) * inv_a;                                        // :19
+    const double tmin = 0.001 * double(len);
+    const double t = (self || t1 < tmin) ? t2 : t1;                              // :18
+    HitRec h;
+    h.t_unit = t;
+    h.px = ox + t * dx; h.py = oy + t * dy; h.pz = oz + t * dz;                  // :27, Ray.cpp:12-14
+    double nx = (h.px - g.cx) * g.inv_r, ny = (h.py - g.cy) * g.inv_r, nz = (h.pz - g.cz) * g.inv_r;   // :28
+    h.front = (dx * nx + dy * ny + dz * nz) < 0.0;                               // Hittable.h:28
+    h.nx = h.front ? nx : -nx; h.ny = h.front ? ny : -ny; h.nz = h.front ? nz : -nz;   // :30
+    h.p = mk3(float(h.px), float(h.py), float(h.pz));
+    h.n = mk3(float(h.nx), float(h.ny), float(h.nz));
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scatter: Lambertian.cpp:5-16, Metal.cpp:6-15, Dielectric.cpp:5-50 computed side by side and
+// blended with selects. dh, len: incoming ray; n: normal opposing the ray; u1,u2: sphere point;
+// u3: Fresnel coin. out is the un-normalised scattered direction, like the reference's.
+// ---------------------------------------------------------------------------------------------
+PT_DEV bool shade(const MatRec& m, f3 dh, float len, f3 n, bool front, float u1, float u2, float u3, f3& out,
+                  f3& atten) {
+    const f3 S = sphere_point(u1, u2);                          // VectorFunc.cpp:37-43
+    const float dn = dot(dh, n);                                // <= 0 by construction of n
+    const f3 refl = fma3(n, -2.0f * dn, dh);                    // VectorFunc.cpp:66-68 on the unit vector
+
+    // Lambertian.cpp:7-10
+    f3 lam = n + S;
+    lam = (dot(lam, lam) <= 1e-30f) ? n : lam;
+    // Metal.cpp:10, :14
+    const f3 met = fma3(S, m.fuzz, refl);
+    const bool met_ok = dot(refl, n) > 0.0f;
+    // Dielectric.cpp:9-37
+    const float ratio = front ? m.inv_ior : m.ior;              // :9
+    const float ct = __builtin_fminf(-dn * len, 1.0f);          // :19, the direction is NOT normalised there
+    const float st = fast_sqrt(__builtin_fmaxf(__builtin_fmaf(-ct, ct, 1.0f), 0.0f));   // :20
+    const bool forbidden = ratio * st > 1.0f;                   // :21
+    const float w = 1.0f - ct;
+    const float w2 = w * w;
+    const float refl_p = __builtin_fmaf(1.0f - m.r0, w2 * w2 * w, m.r0);   // :46-50
+    const bool do_reflect = forbidden | (refl_p > u3);          // :27, :30
+    // VectorFunc.cpp:70-76
+    const float ct2 = __builtin_fminf(-dn, 1.0f);
+    const f3 perp = fma3(n, ct2, dh) * ratio;
+    const float par = -fast_sqrt(__builtin_fabsf(1.0f - dot(perp, perp)));
+    const f3 refr = fma3(n, par, perp);
+    const f3 die = select3(do_reflect, refl, refr);
+
+    const bool is_lam = m.kind == 0, is_met = m.kind == 1;
+    out = select3(is_lam, lam, select3(is_met, met, die));
+    atten = (m.kind == 2) ? mk3(1.0f, 1.0f, 1.0f) : mk3(m.ar, m.ag, m.ab);   // Lambertian.cpp:14, Metal.cpp:11, Dielectric.cpp:7
+    return is_met ? met_ok : true;
+}
+
+// Normalise a direction: returns the unit vector, writes the length.
+PT_DEV f3 normalise(f3 d, float& len) {
+    const float l2 = dot(d, d);
+    const float inv = __builtin_amdgcn_rsqf(l2);
+    len = l2 * inv;
+    return d * inv;
+}
+
+}   // namespace ptd

@@ -1,0 +1,702 @@
+// pt_hip.hip — kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h).
+//
+// Kernels
+//   k_render   the sample loop: per-lane iterative bounce loop with path regeneration. One wave
+//              (one 64-thread workgroup) takes a job = an 8x8 pixel tile x a chunk of samples and
+//              hands (pixel, sample) items to its lanes as their paths end, so every lane stays
+//              inside the sphere scan. Replaces process_row / sumColour / calcColour
+//              (Path Tracer.cpp:296-300, :265-278, :82-108).
+//   k_resolve  converts the job sums (64-bit fixed point, order-independent) to float and adds
+//              them into the caller's accumulation buffer.
+//   k_scan / k_scatter / k_gen_ray / k_sky / k_philox   the same device functions, one thread
+//              per element, behind the unit-test entry points.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_hip.h"
+#include "pt_device.h"
+
+using namespace ptd;
+
+// =============================================================================================
+// Device side
+// =============================================================================================
+struct RenderParams {
+    int W, H;
+    int spp_begin, spp_end, spp_chunk, n_chunks;
+    int tiles_x;
+    int max_depth;
+    uint32_t key0, key1;
+    float inv_w1, inv_h1;
+    CameraDev cam;
+    SceneDev scene;
+    unsigned long long* accum_fx;    // [H][W][3] fixed-point (2^-32) sums, top row first
+    unsigned long long* ray_count;   // rays of this call
+};
+
+// Radiance in [0, 1] per channel (every attenuation and the sky are <= 1) to unsigned Q32.32.
+// Integer sums make the frame independent of the order in which lanes and jobs finish.
+PT_DEV unsigned long long to_fx(float v) {
+    v = (v >= 0.0f) ? v : 0.0f;          // also drops a NaN
+    v = __builtin_fminf(v, 65536.0f);
+    return (unsigned long long)(v * 4294967296.0f);
+}
+
+__global__ void __launch_bounds__(64) k_render(const RenderParams P) {
+    __shared__ unsigned long long acc[64 * 3];
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
+    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const int s0 = P.spp_begin + chunk * P.spp_chunk;
+    const int s1 = min(s0 + P.spp_chunk, P.spp_end);
+    const int total = 64 * (s1 - s0);        // items of this job: (sample, slot)
+    acc[lane * 3 + 0] = 0; acc[lane * 3 + 1] = 0; acc[lane * 3 + 2] = 0;
+
+    int next = 0;                            // wave-uniform: first item not handed out yet
+    bool active = false, exhausted = false;
+    unsigned int rays = 0;
+
+    // path state
+    f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(1, 1, 1);
+    float len = 1.0f;
+    int slot = 0, bounce = 0, prev = -1;
+    uint32_t pixel = 0, sample = 0;
+
+    for (;;) {
+        // ---- hand new items to the lanes whose path has ended (regeneration) ----
+        bool need = !active && !exhausted;
+        while (__any(need)) {
+            const unsigned long long m = __ballot(need);
+            const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0));
+            const int k = next + rank;
+            next += __popcll(m);
+            if (need) {
+                if (k >= total) {
+                    exhausted = true;
+                    need = false;
+                } else {
+                    slot = k & 63;
+                    const int px = tx * 8 + (slot & 7), py = ty * 8 + (slot >> 3);   // py from the top
+                    if (px < P.W && py < P.H) {
+                        const int j = P.H - 1 - py;                                  // Path Tracer.cpp:298
+                        pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
+                        sample = uint32_t(s0 + (k >> 6));
+                        const u4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
+                        // jitter, then a polar map of two uniforms onto the unit disk (same distribution
+                        // as the rejection loop of VectorFunc.cpp:57-64)
+                        const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
+                        f3 d;
+                        gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang),
+                                rad * sin_rev(ang), o, d);
+                        dh = normalise(d, len);
+                        thr = mk3(1, 1, 1);
+                        bounce = 0;
+                        prev = -1;
+                        active = P.max_depth > 0;                                    // Path Tracer.cpp:86
+                        need = !active;
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+
+        // ---- one ray of every live path ----
+        if (active) {
+            ++rays;
+            float bt; int bi;
+            scan_spheres(P.scene, o, dh, 0.001f * len, prev, bt, bi);
+            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
+                const f3 c = thr * sky(dh.y);
+                atomicAdd(&acc[slot * 3 + 0], to_fx(c.x));
+                atomicAdd(&acc[slot * 3 + 1], to_fx(c.y));
+                atomicAdd(&acc[slot * 3 + 2], to_fx(c.z));
+                active = false;
+            } else {
+                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, len);
+                const MatRec m = P.scene.mat[bi];
+                const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce) + 1u, 0u, P.key0, P.key1);
+                f3 d, atten;
+                const bool ok = shade(m, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
+                thr = thr * atten;                                                   // Path Tracer.cpp:97
+                o = h.p;
+                dh = normalise(d, len);
+                prev = bi;
+                ++bounce;
+                active = ok && bounce < P.max_depth;                                 // :100, :86 -> black
+            }
+        }
+    }
+
+    // ---- job sums to the frame ----
+    {
+        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+        if (px < P.W && py < P.H) {
+            unsigned long long* dst = P.accum_fx + (size_t(py) * size_t(P.W) + size_t(px)) * 3;
+            atomicAdd(dst + 0, acc[lane * 3 + 0]);
+            atomicAdd(dst + 1, acc[lane * 3 + 1]);
+            atomicAdd(dst + 2, acc[lane * 3 + 2]);
+        }
+        unsigned int r = rays;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
+        if (lane == 0) atomicAdd(P.ray_count, (unsigned long long)r);
+    }
+}
+
+__global__ void k_resolve(unsigned long long* fx, float* out, size_t n, const unsigned long long* call_rays,
+                          unsigned long long* total_rays) {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long v = fx[i];
+        if (v) {
+            out[i] += float(double(v) * (1.0 / 4294967296.0));
+            fx[i] = 0;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total_rays += *call_rays;
+}
+
+__global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, double t_min, double* t, int* idx,
+                       double* p, double* nrm, int* front) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const f3 ro = mk3(float(o[3 * k]), float(o[3 * k + 1]), float(o[3 * k + 2]));
+    const f3 rd = mk3(float(d[3 * k]), float(d[3 * k + 1]), float(d[3 * k + 2]));
+    float len;
+    const f3 dh = normalise(rd, len);
+    float bt; int bi;
+    scan_spheres(sc, ro, dh, float(t_min) * len, -1, bt, bi);
+    idx[k] = bi;
+    if (bi < 0) {
+        t[k] = 0; front[k] = 0;
+        for (int c = 0; c < 3; ++c) { p[3 * k + c] = 0; nrm[3 * k + c] = 0; }
+        return;
+    }
+    const HitRec h = finish_hit(sc, bi, false, ro, dh, len);
+    t[k] = h.t_unit / double(len);
+    p[3 * k] = h.px; p[3 * k + 1] = h.py; p[3 * k + 2] = h.pz;
+    nrm[3 * k] = h.nx; nrm[3 * k + 1] = h.ny; nrm[3 * k + 2] = h.nz;
+    front[k] = h.front ? 1 : 0;
+}
+
+__global__ void k_scatter(int n, const int* kind, const double* albedo, const double* fuzz, const double* ior,
+                          const double* d_in, const double* nrm, const int* front, const double* u, double* d_out,
+                          double* atten, int* ok) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    MatRec m;
+    m.ar = float(albedo[3 * k]); m.ag = float(albedo[3 * k + 1]); m.ab = float(albedo[3 * k + 2]);
+    m.fuzz = float(fuzz[k]);
+    const double i = ior[k];
+    m.ior = float(i);
+    m.inv_ior = i != 0.0 ? float(1.0 / i) : 0.0f;
+    const double r0 = (1.0 - i) / (1.0 + i);
+    m.r0 = float(r0 * r0);
+    m.kind = kind[k];
+    float len;
+    const f3 dh = normalise(mk3(float(d_in[3 * k]), float(d_in[3 * k + 1]), float(d_in[3 * k + 2])), len);
+    const f3 nn = mk3(float(nrm[3 * k]), float(nrm[3 * k + 1]), float(nrm[3 * k + 2]));
+    f3 out, a;
+    const bool r = shade(m, dh, len, nn, front[k] != 0, float(u[3 * k]), float(u[3 * k + 1]), float(u[3 * k + 2]), out, a);
+    d_out[3 * k] = out.x; d_out[3 * k + 1] = out.y; d_out[3 * k + 2] = out.z;
+    atten[3 * k] = a.x; atten[3 * k + 1] = a.y; atten[3 * k + 2] = a.z;
+    ok[k] = r ? 1 : 0;
+}
+
+__global__ void k_gen_ray(CameraDev cam, int n, float inv_w1, float inv_h1, const int* pi, const int* pj,
+                          const double* u1, const double* u2, const double* diskx, const double* disky, double* o,
+                          double* d) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    f3 ro, rd;
+    gen_ray(cam, pi[k], pj[k], inv_w1, inv_h1, float(u1[k]), float(u2[k]), float(diskx[k]), float(disky[k]), ro, rd);
+    o[3 * k] = ro.x; o[3 * k + 1] = ro.y; o[3 * k + 2] = ro.z;
+    d[3 * k] = rd.x; d[3 * k + 1] = rd.y; d[3 * k + 2] = rd.z;
+}
+
+__global__ void k_sky(int n, const double* d, double* rgb) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float len;
+    const f3 dh = normalise(mk3(float(d[3 * k]), float(d[3 * k + 1]), float(d[3 * k + 2])), len);
+    const f3 c = sky(dh.y);
+    rgb[3 * k] = c.x; rgb[3 * k + 1] = c.y; rgb[3 * k + 2] = c.z;
+}
+
+__global__ void k_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, uint32_t* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const u4 r = philox4x32_10(ctr[4 * k], ctr[4 * k + 1], ctr[4 * k + 2], ctr[4 * k + 3], k0, k1);
+    out[4 * k] = r.x; out[4 * k + 1] = r.y; out[4 * k + 2] = r.z; out[4 * k + 3] = r.w;
+}
+
+// =============================================================================================
+// Host side: the context and the C-ABI
+// =============================================================================================
+struct pt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    float* d_scan = nullptr;
+    GeomRec* d_geom = nullptr;
+    MatRec* d_mat = nullptr;
+    int n = 0, n_pad = 0;
+    bool have_scene = false, have_camera = false;
+    CameraDev cam;
+    // frame
+    unsigned long long* d_fx = nullptr;
+    size_t fx_elems = 0;
+    float* d_accum = nullptr;
+    int acc_w = 0, acc_h = 0;
+    unsigned long long* d_counters = nullptr;   // [0] rays of the current call, [1] rays since creation
+    // kernel timing
+    std::vector<hipEvent_t> ev;                 // pairs
+    size_t ev_used = 0;
+    int target_jobs = 65536;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(pt_handle h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+#define PT_HIP(h, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(h, PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T>
+static int upload(pt_handle h, T** dst, const std::vector<T>& src) {
+    if (*dst) { PT_HIP(h, hipFree(*dst)); *dst = nullptr; }
+    PT_HIP(h, hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * src.size()));
+    PT_HIP(h, hipMemcpyAsync(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// Scoped device buffer for the unit-test entry points.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+static SceneDev scene_dev(pt_handle h) {
+    SceneDev s;
+    s.scan = h->d_scan; s.geom = h->d_geom; s.mat = h->d_mat; s.n = h->n; s.n_pad = h->n_pad;
+    return s;
+}
+
+extern "C" {
+
+const char* pt_last_error(pt_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int pt_create(int device_index, pt_handle* out) {
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, PT_ERR_HIP, std::string("pt_create: no HIP device (") + hipGetErrorString(e) +
+                                             "); this library has no CPU path");
+    if (device_index < 0 || device_index >= count) return fail(nullptr, PT_ERR_INVALID, "pt_create: device index out of range");
+    hipDeviceProp_t prop;
+    PT_HIP(nullptr, hipGetDeviceProperties(&prop, device_index));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PT_ERR_INVALID, std::string("pt_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    pt_context* h = new (std::nothrow) pt_context;
+    if (!h) return fail(nullptr, PT_ERR_INVALID, "pt_create: out of host memory");
+    h->device = device_index;
+    PT_HIP(nullptr, hipSetDevice(device_index));
+    e = hipStreamCreate(&h->own_stream);
+    if (e != hipSuccess) { delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
+    *out = h;
+    return 0;
+}
+
+int pt_destroy(pt_handle h) {
+    if (!h) return PT_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
+    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters);
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+int pt_set_stream(pt_handle h, void* hip_stream) {
+    if (!h) return PT_ERR_INVALID;
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return 0;
+}
+
+int pt_synchronize(pt_handle h) {
+    if (!h) return PT_ERR_INVALID;
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const double* cz, const double* r,
+                 const int* kind, const double* ar, const double* ag, const double* ab, const double* fuzz,
+                 const double* ior) {
+    if (!h) return PT_ERR_INVALID;
+    if (n <= 0 || !cx || !cy || !cz || !r || !kind || !ar || !ag || !ab || !fuzz || !ior)
+        return fail(h, PT_ERR_INVALID, "pt_set_scene: n must be positive and no array may be NULL");
+    for (int i = 0; i < n; ++i) {
+        if (kind[i] < 0 || kind[i] > 2) return fail(h, PT_ERR_INVALID, "pt_set_scene: unknown material kind");
+        if (!(r[i] > 0.0) || !std::isfinite(r[i]) || !std::isfinite(cx[i]) || !std::isfinite(cy[i]) || !std::isfinite(cz[i]))
+            return fail(h, PT_ERR_INVALID, "pt_set_scene: sphere with non-finite centre or non-positive radius");
+        if (kind[i] == PT_DIELECTRIC && !(ior[i] > 0.0)) return fail(h, PT_ERR_INVALID, "pt_set_scene: dielectric with non-positive refractive index");
+    }
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    const int n_pad = (n + 3) & ~3;
+    std::vector<float> scan(size_t(n_pad) * 4);
+    std::vector<GeomRec> geom(n);
+    std::vector<MatRec> mat(n);
+    for (int i = 0; i < n_pad; ++i) {
+        float* rec = scan.data() + 8 * (i >> 1) + (i & 1);
+        if (i < n) {
+            rec[0] = float(cx[i]); rec[2] = float(cy[i]); rec[4] = float(cz[i]);
+            // K from the float centre the scan multiplies with, so that b*b + 2 o.c - |o|^2 - K is
+            // the discriminant of the sphere tier 1 actually sees; r^2 in double.
+            const double fx = rec[0], fy = rec[2], fz = rec[4];
+            rec[6] = float(fx * fx + fy * fy + fz * fz - r[i] * r[i]);
+        } else {
+            rec[0] = rec[2] = rec[4] = 0.0f;
+            rec[6] = 1e30f;                      // never flagged
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        geom[i] = GeomRec{cx[i], cy[i], cz[i], r[i], 1 / r[i], r[i] * r[i]};   // Sphere.cpp:9, :28
+        MatRec m;
+        m.ar = float(ar[i]); m.ag = float(ag[i]); m.ab = float(ab[i]);
+        m.fuzz = float(fuzz[i] < 1 ? fuzz[i] : 1);                              // Metal.h:21
+        const double ii = kind[i] == PT_DIELECTRIC ? ior[i] : 1.0;
+        m.ior = float(ii); m.inv_ior = float(1.0 / ii);
+        const double r0 = (1 - ii) / (1 + ii);
+        m.r0 = float(r0 * r0);
+        m.kind = kind[i];
+        mat[i] = m;
+    }
+    int rc;
+    if ((rc = upload(h, &h->d_scan, scan))) return rc;
+    if ((rc = upload(h, &h->d_geom, geom))) return rc;
+    if ((rc = upload(h, &h->d_mat, mat))) return rc;
+    h->n = n; h->n_pad = n_pad; h->have_scene = true;
+    return 0;
+}
+
+int pt_set_camera(pt_handle h, const double position[3], const double lower_left[3], const double horizontal[3],
+                  const double vertical[3], const double u[3], const double v[3], double lens_radius) {
+    if (!h) return PT_ERR_INVALID;
+    if (!position || !lower_left || !horizontal || !vertical || !u || !v) return fail(h, PT_ERR_INVALID, "pt_set_camera: NULL vector");
+    auto f = [](const double* a) { return f3{float(a[0]), float(a[1]), float(a[2])}; };
+    h->cam.pos = f(position);
+    const double rel[3] = {lower_left[0] - position[0], lower_left[1] - position[1], lower_left[2] - position[2]};
+    h->cam.ll_rel = f(rel);
+    h->cam.hor = f(horizontal); h->cam.ver = f(vertical); h->cam.u = f(u); h->cam.v = f(v);
+    h->cam.lens = float(lens_radius);
+    h->have_camera = true;
+    return 0;
+}
+
+int pt_clear_accum(pt_handle h, int width, int height) {
+    if (!h) return PT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || size_t(width) * size_t(height) > (size_t(1) << 28))
+        return fail(h, PT_ERR_INVALID, "pt_clear_accum: bad image size");
+    PT_HIP(h, hipSetDevice(h->device));
+    const size_t n = size_t(width) * height * 3;
+    if (width != h->acc_w || height != h->acc_h || !h->d_accum) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_accum) { PT_HIP(h, hipFree(h->d_accum)); h->d_accum = nullptr; }
+        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_accum), n * sizeof(float)));
+        h->acc_w = width; h->acc_h = height;
+    }
+    PT_HIP(h, hipMemsetAsync(h->d_accum, 0, n * sizeof(float), h->stream));
+    return 0;
+}
+
+void* pt_accum_device_ptr(pt_handle h) { return h ? h->d_accum : nullptr; }
+
+int pt_read_accum(pt_handle h, float* host_f32) {
+    if (!h || !host_f32) return PT_ERR_INVALID;
+    if (!h->d_accum) return fail(h, PT_ERR_STATE, "pt_read_accum: no accumulation buffer (call pt_clear_accum or pt_render first)");
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipMemcpyAsync(host_f32, h->d_accum, size_t(h->acc_w) * h->acc_h * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
+              float* accum_rgb_f32, uint64_t* ray_count_out) {
+    if (!h) return PT_ERR_INVALID;
+    if (!h->have_scene || !h->have_camera) return fail(h, PT_ERR_STATE, "pt_render: set the scene and the camera first");
+    if (width <= 0 || height <= 0 || size_t(width) * size_t(height) > (size_t(1) << 28)) return fail(h, PT_ERR_INVALID, "pt_render: bad image size");
+    if (spp_begin < 0 || spp_end < spp_begin) return fail(h, PT_ERR_INVALID, "pt_render: bad sample range");
+    if (max_depth < 0) return fail(h, PT_ERR_INVALID, "pt_render: negative max_depth");
+    PT_HIP(h, hipSetDevice(h->device));
+    float* out = accum_rgb_f32;
+    if (!out) {
+        if (!h->d_accum || h->acc_w != width || h->acc_h != height) {
+            int rc = pt_clear_accum(h, width, height);
+            if (rc) return rc;
+        }
+        out = h->d_accum;
+    }
+    const size_t n_elems = size_t(width) * height * 3;
+    if (h->fx_elems < n_elems) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_fx) { PT_HIP(h, hipFree(h->d_fx)); h->d_fx = nullptr; h->fx_elems = 0; }
+        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_fx), n_elems * sizeof(unsigned long long)));
+        PT_HIP(h, hipMemsetAsync(h->d_fx, 0, n_elems * sizeof(unsigned long long), h->stream));
+        h->fx_elems = n_elems;
+    }
+    PT_HIP(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long), h->stream));
+    const int spp = spp_end - spp_begin;
+    if (spp > 0) {
+        RenderParams P;
+        P.W = width; P.H = height;
+        P.spp_begin = spp_begin; P.spp_end = spp_end;
+        P.tiles_x = (width + 7) / 8;
+        const long long tiles = (long long)P.tiles_x * ((height + 7) / 8);
+        long long want = (h->target_jobs + tiles - 1) / tiles;
+        if (want < 1) want = 1;
+        if (want > spp) want = spp;
+        P.spp_chunk = int((spp + want - 1) / want);
+        P.n_chunks = (spp + P.spp_chunk - 1) / P.spp_chunk;
+        const long long jobs = tiles * P.n_chunks;
+        if (jobs > 0x7fffffffLL) return fail(h, PT_ERR_INVALID, "pt_render: too many jobs for one launch");
+        P.max_depth = max_depth;
+        P.key0 = uint32_t(seed); P.key1 = uint32_t(seed >> 32);
+        // (W - 1) and (H - 1) divide by zero for a one-pixel-wide image in the reference too
+        // (Path Tracer.cpp:270-271); the float reciprocal is inf there as well.
+        P.inv_w1 = 1.0f / float(width - 1); P.inv_h1 = 1.0f / float(height - 1);
+        P.cam = h->cam;
+        P.scene = scene_dev(h);
+        P.accum_fx = h->d_fx;
+        P.ray_count = h->d_counters;
+        const bool timed = h->ev_used + 2 <= 8192;
+        if (timed && h->ev.size() < h->ev_used + 2) {
+            hipEvent_t a, b;
+            PT_HIP(h, hipEventCreate(&a)); PT_HIP(h, hipEventCreate(&b));
+            h->ev.push_back(a); h->ev.push_back(b);
+        }
+        if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+        hipLaunchKernelGGL(k_render, dim3(unsigned(jobs)), dim3(64), 0, h->stream, P);
+        PT_HIP(h, hipGetLastError());
+        if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+    }
+    {
+        const unsigned blocks = unsigned(std::min<size_t>((n_elems + 255) / 256, 256 * 16));
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_elems, h->d_counters, h->d_counters + 1);
+        PT_HIP(h, hipGetLastError());
+    }
+    if (ray_count_out) {
+        unsigned long long v = 0;
+        PT_HIP(h, hipMemcpyAsync(&v, h->d_counters, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        *ray_count_out = v;
+    }
+    return 0;
+}
+
+int pt_ray_count(pt_handle h, uint64_t* out) {
+    if (!h || !out) return PT_ERR_INVALID;
+    PT_HIP(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    PT_HIP(h, hipMemcpyAsync(&v, h->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    *out = v;
+    return 0;
+}
+
+int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n) {
+    if (!h || !n || (cap > 0 && !out_ms)) return PT_ERR_INVALID;
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    const int count = int(h->ev_used / 2);
+    for (int i = 0; i < count && i < cap; ++i) PT_HIP(h, hipEventElapsedTime(&out_ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    *n = count;
+    h->ev_used = 0;
+    return 0;
+}
+
+// ---- RCCL reduce of the own accumulation buffers, single process, one handle per GPU ----
+int pt_reduce(pt_handle* handles, int n, int root) {
+    if (!handles || n <= 0 || root < 0 || root >= n) return PT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i] || !handles[i]->d_accum) return fail(handles[0], PT_ERR_STATE, "pt_reduce: a handle has no accumulation buffer");
+        if (handles[i]->acc_w != handles[0]->acc_w || handles[i]->acc_h != handles[0]->acc_h)
+            return fail(handles[0], PT_ERR_INVALID, "pt_reduce: accumulation buffers differ in size");
+    }
+    if (n == 1) return 0;
+    pt_handle h0 = handles[0];
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(h0, PT_ERR_RCCL, std::string("pt_reduce: cannot load librccl: ") + dlerror());
+    typedef void* comm_t;
+    typedef int (*init_all_t)(comm_t*, int, const int*);
+    typedef int (*reduce_t)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t);
+    typedef int (*void_t)();
+    typedef int (*destroy_t)(comm_t);
+    init_all_t init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
+    reduce_t reduce = (reduce_t)dlsym(lib, "ncclReduce");
+    void_t gstart = (void_t)dlsym(lib, "ncclGroupStart");
+    void_t gend = (void_t)dlsym(lib, "ncclGroupEnd");
+    destroy_t destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!init_all || !reduce || !gstart || !gend || !destroy) return fail(h0, PT_ERR_RCCL, "pt_reduce: librccl lacks an expected symbol");
+    std::vector<comm_t> comms(n);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) devs[i] = handles[i]->device;
+    if (init_all(comms.data(), n, devs.data()) != 0) return fail(h0, PT_ERR_RCCL, "pt_reduce: ncclCommInitAll failed");
+    const size_t count = size_t(h0->acc_w) * h0->acc_h * 3;
+    int rc = 0;
+    const int ncclFloat32 = 7, ncclSum = 0;
+    if (gstart() != 0) rc = PT_ERR_RCCL;
+    for (int i = 0; i < n && !rc; ++i) {
+        (void)hipSetDevice(handles[i]->device);
+        if (reduce(handles[i]->d_accum, handles[i]->d_accum, count, ncclFloat32, ncclSum, root, comms[i], handles[i]->stream) != 0) rc = PT_ERR_RCCL;
+    }
+    if (gend() != 0) rc = PT_ERR_RCCL;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(handles[i]->device);
+        (void)hipStreamSynchronize(handles[i]->stream);
+        (void)destroy(comms[i]);
+    }
+    if (rc) return fail(h0, rc, "pt_reduce: ncclReduce failed");
+    return 0;
+}
+
+// ---- unit-test entry points ----
+#define PT_ALLOC_COPY(buf, ptr, bytes)                                                              \
+    do {                                                                                            \
+        PT_HIP(h, buf.alloc(bytes));                                                                \
+        if (ptr) PT_HIP(h, hipMemcpyAsync(buf.p, ptr, bytes, hipMemcpyHostToDevice, h->stream));    \
+    } while (0)
+#define PT_COPY_BACK(ptr, buf, bytes) PT_HIP(h, hipMemcpyAsync(ptr, buf.p, bytes, hipMemcpyDeviceToHost, h->stream))
+
+int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, double* t, int* idx, double* p,
+            double* nrm, int* front) {
+    if (!h) return PT_ERR_INVALID;
+    if (!h->have_scene) return fail(h, PT_ERR_STATE, "pt_scan: set the scene first");
+    if (n < 0 || (n > 0 && (!o || !d || !t || !idx || !p || !nrm || !front))) return fail(h, PT_ERR_INVALID, "pt_scan: bad arguments");
+    if (n == 0) return 0;
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bo, bd, bt, bi, bp, bn, bf;
+    const size_t v3 = size_t(n) * 3 * sizeof(double);
+    PT_ALLOC_COPY(bo, o, v3); PT_ALLOC_COPY(bd, d, v3);
+    PT_ALLOC_COPY(bt, (void*)nullptr, n * sizeof(double)); PT_ALLOC_COPY(bi, (void*)nullptr, n * sizeof(int));
+    PT_ALLOC_COPY(bp, (void*)nullptr, v3); PT_ALLOC_COPY(bn, (void*)nullptr, v3); PT_ALLOC_COPY(bf, (void*)nullptr, n * sizeof(int));
+    hipLaunchKernelGGL(k_scan, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), n, bo.as<double>(), bd.as<double>(), t_min,
+                       bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(t, bt, n * sizeof(double)); PT_COPY_BACK(idx, bi, n * sizeof(int));
+    PT_COPY_BACK(p, bp, v3); PT_COPY_BACK(nrm, bn, v3); PT_COPY_BACK(front, bf, n * sizeof(int));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_scatter(pt_handle h, int n, const int* kind, const double* albedo, const double* fuzz, const double* ior,
+               const double* d_in, const double* p, const double* nrm, const int* front, const double* u,
+               double* d_out, double* atten, int* ok) {
+    (void)p;   // the scattered ray starts at the hit point unchanged (Lambertian.cpp:13, Metal.cpp:10, Dielectric.cpp:41)
+    if (!h) return PT_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!kind || !albedo || !fuzz || !ior || !d_in || !nrm || !front || !u || !d_out || !atten || !ok)))
+        return fail(h, PT_ERR_INVALID, "pt_scatter: bad arguments");
+    if (n == 0) return 0;
+    for (int i = 0; i < n; ++i) if (kind[i] < 0 || kind[i] > 2) return fail(h, PT_ERR_INVALID, "pt_scatter: unknown material kind");
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bk, ba, bfz, bio, bd, bn, bfr, bu, bdo, bat, bok;
+    const size_t v3 = size_t(n) * 3 * sizeof(double), s1 = size_t(n) * sizeof(double), i1 = size_t(n) * sizeof(int);
+    PT_ALLOC_COPY(bk, kind, i1); PT_ALLOC_COPY(ba, albedo, v3); PT_ALLOC_COPY(bfz, fuzz, s1); PT_ALLOC_COPY(bio, ior, s1);
+    PT_ALLOC_COPY(bd, d_in, v3); PT_ALLOC_COPY(bn, nrm, v3); PT_ALLOC_COPY(bfr, front, i1); PT_ALLOC_COPY(bu, u, v3);
+    PT_ALLOC_COPY(bdo, (void*)nullptr, v3); PT_ALLOC_COPY(bat, (void*)nullptr, v3); PT_ALLOC_COPY(bok, (void*)nullptr, i1);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, bk.as<int>(), ba.as<double>(), bfz.as<double>(),
+                       bio.as<double>(), bd.as<double>(), bn.as<double>(), bfr.as<int>(), bu.as<double>(), bdo.as<double>(),
+                       bat.as<double>(), bok.as<int>());
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(d_out, bdo, v3); PT_COPY_BACK(atten, bat, v3); PT_COPY_BACK(ok, bok, i1);
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_gen_ray(pt_handle h, int n, int width, int height, const int* pi, const int* pj, const double* u1,
+               const double* u2, const double* diskx, const double* disky, double* o, double* d) {
+    if (!h) return PT_ERR_INVALID;
+    if (!h->have_camera) return fail(h, PT_ERR_STATE, "pt_gen_ray: set the camera first");
+    if (n < 0 || width <= 0 || height <= 0 || (n > 0 && (!pi || !pj || !u1 || !u2 || !diskx || !disky || !o || !d)))
+        return fail(h, PT_ERR_INVALID, "pt_gen_ray: bad arguments");
+    if (n == 0) return 0;
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bi, bj, b1, b2, bx, by, bo, bd;
+    const size_t v3 = size_t(n) * 3 * sizeof(double), s1 = size_t(n) * sizeof(double), i1 = size_t(n) * sizeof(int);
+    PT_ALLOC_COPY(bi, pi, i1); PT_ALLOC_COPY(bj, pj, i1); PT_ALLOC_COPY(b1, u1, s1); PT_ALLOC_COPY(b2, u2, s1);
+    PT_ALLOC_COPY(bx, diskx, s1); PT_ALLOC_COPY(by, disky, s1);
+    PT_ALLOC_COPY(bo, (void*)nullptr, v3); PT_ALLOC_COPY(bd, (void*)nullptr, v3);
+    hipLaunchKernelGGL(k_gen_ray, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->cam, n, 1.0f / float(width - 1),
+                       1.0f / float(height - 1), bi.as<int>(), bj.as<int>(), b1.as<double>(), b2.as<double>(), bx.as<double>(),
+                       by.as<double>(), bo.as<double>(), bd.as<double>());
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(o, bo, v3); PT_COPY_BACK(d, bd, v3);
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_sky(pt_handle h, int n, const double* d, double* rgb) {
+    if (!h) return PT_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!d || !rgb))) return fail(h, PT_ERR_INVALID, "pt_sky: bad arguments");
+    if (n == 0) return 0;
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bd, bc;
+    const size_t v3 = size_t(n) * 3 * sizeof(double);
+    PT_ALLOC_COPY(bd, d, v3); PT_ALLOC_COPY(bc, (void*)nullptr, v3);
+    hipLaunchKernelGGL(k_sky, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, bd.as<double>(), bc.as<double>());
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(rgb, bc, v3);
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_philox(pt_handle h, int n, const uint32_t* ctr, const uint32_t key[2], uint32_t* out) {
+    if (!h) return PT_ERR_INVALID;
+    if (n < 0 || !key || (n > 0 && (!ctr || !out))) return fail(h, PT_ERR_INVALID, "pt_philox: bad arguments");
+    if (n == 0) return 0;
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bc, bo;
+    const size_t b = size_t(n) * 4 * sizeof(uint32_t);
+    PT_ALLOC_COPY(bc, ctr, b); PT_ALLOC_COPY(bo, (void*)nullptr, b);
+    hipLaunchKernelGGL(k_philox, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, bc.as<uint32_t>(), key[0], key[1], bo.as<uint32_t>());
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(out, bo, b);
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}   // extern "C"
