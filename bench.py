@@ -71,6 +71,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from path_tracer_amd import distributed as ptd
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,9 +83,7 @@ def main():
         print("bench.py: no GPU visible; the sample loop has no CPU path", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ptd.init("nccl")          # RCCL; a single process needs no group
 
     from path_tracer_amd import Device, host
 
@@ -97,13 +96,12 @@ def main():
     dev.set_camera(cam)
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-    spp_begin, spp_end = rank * spp, (rank + 1) * spp     # disjoint ranges of one frame
+    spp_begin, spp_end = ptd.weak_range(rank, spp)        # disjoint ranges of one frame
 
     def step():
         accum.zero_()
         dev.render(W, H, spp_begin, spp_end, depth, 42, accum_ptr=accum.data_ptr())
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        ptd.reduce_frame(accum, dst=0)
 
     def fence():
         torch.cuda.synchronize()

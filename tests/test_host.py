@@ -1,0 +1,163 @@
+"""CPU: the host-side C++ that keeps the reference's interfaces (config reader, readVector, camera
+set-up, scene generator, PPM writer), against the reference's own config.txt semantics, the oracle
+and the hand-derived known answers."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from path_tracer_amd import host
+
+REFERENCE_CONFIG = """###Path Tracer Configuration File###
+
+#The # symbol denotes comments which are ignored by the program.
+#Layout of this file must be single lines of "[Variable Name] = [value]". By default, white space is ignored.
+
+#Image Settings
+imageAspectRatio = 1.7777777777 \t#Can't parse a ratio format so we do the division. Default: 1.777777777 (16:9)
+imageWidth \t = 400\t\t\t#Measured in pixels. Default: 400.
+
+#Simulation Settings
+raysPerPixel\t = 100\t\t\t#Number of slightly randomised rays per pixel, for antialiasing. Default: 100
+materialMaxDepth = 50\t\t\t#Number of reflections/refractions a single ray can undergo.\t Default: 50
+numberOfThreads  = 8\t\t\t#Number of threads to use in the simulation step.\t\t Default: 4
+
+#Camera Settings
+#Vectors must be in the form of (X,Y,Z)
+
+cameraPosition \t = (8,2,3)\t\t#Default: (8,2,3)
+cameraLookingAt\t = (0,0,0)\t\t#Default: (0,0,0)
+cameraUpOrient\t = (0,1,0)\t\t#Default: (0,1,0)
+focalLength\t = 1\t\t\t#Default: 1
+verticalFOV\t = 60\t\t\t#Measured in degrees. Default: 60
+apertureSize\t = 0.1\t\t\t#Default 0.1
+"""   # same keys, values, tabs and trailing comments as the reference's config.txt:1-23
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        return json.load(f)
+
+
+def test_reads_the_reference_config():
+    s, used_defaults = host.read_settings(REFERENCE_CONFIG)
+    assert not used_defaults
+    assert s["imageAspectRatio"] == 1.7777777777 and s["imageWidth"] == 400 and s["imageHeight"] == 225
+    assert s["raysPerPixel"] == 100 and s["materialMaxDepth"] == 50
+    assert s["cameraPosition"] == (8, 2, 3) and s["cameraLookingAt"] == (0, 0, 0) and s["cameraUpOrient"] == (0, 1, 0)
+    assert s["focalLength"] == 1 and s["verticalFOV"] == 60 and s["apertureSize"] == 0.1
+
+
+def test_config_values_override_defaults():
+    txt = REFERENCE_CONFIG.replace("= 400", "= 1920").replace("= 100\t", "= 7\t").replace("(8,2,3)\t", "(3,4,5.5)\t")
+    s, used_defaults = host.read_settings(txt)
+    assert not used_defaults and s["imageWidth"] == 1920 and s["raysPerPixel"] == 7 and s["cameraPosition"] == (3, 4, 5.5)
+    assert s["imageHeight"] == 1080
+
+
+def test_focus_distance_is_frozen_at_the_default_camera(kat):
+    # Path Tracer.cpp:127: computed before the file is read, never updated.
+    txt = REFERENCE_CONFIG.replace("(8,2,3)\t", "(1,1,1)\t")
+    s, _ = host.read_settings(txt)
+    assert s["cameraPosition"] == (1, 1, 1) and s["focusDistance"] == kat["focus_distance"]["value"]
+
+
+def test_all_or_nothing_fallback():
+    # A missing key throws inside the try block: every value goes back to its default (Path Tracer.cpp:158-173) ...
+    txt = REFERENCE_CONFIG.replace("apertureSize", "apertureSizeX").replace("= 400", "= 1234")
+    s, used_defaults = host.read_settings(txt)
+    assert used_defaults and s["imageWidth"] == 400 and s["apertureSize"] == 0.1
+    # ... except cameraUpOrient, which the catch block does not reset (absent from :163-172).
+    txt = REFERENCE_CONFIG.replace("(0,1,0)\t", "(1,0,0)\t").replace("apertureSize", "apertureSizeX")
+    s, used_defaults = host.read_settings(txt)
+    assert used_defaults and s["cameraUpOrient"] == (1, 0, 0)
+    for bad in ["this line has no equals sign\n", "imageWidth = forty\n" + REFERENCE_CONFIG.replace("imageWidth", "x"), ""]:
+        s, used_defaults = host.read_settings(bad)
+        assert used_defaults and s["imageWidth"] == 400 and s["raysPerPixel"] == 100
+
+
+def test_number_of_threads_key_is_ignored():
+    s1, _ = host.read_settings(REFERENCE_CONFIG)
+    s2, _ = host.read_settings(REFERENCE_CONFIG.replace("numberOfThreads  = 8", "numberOfThreads  = 1"))
+    assert s1 == s2
+
+
+def test_read_vector_accepts_unsigned_decimals_only():
+    assert host.read_vector("(8,2,3)") == (True, (8, 2, 3))
+    assert host.read_vector("[1.5,2.,3.25]") == (True, (1.5, 2.0, 3.25))
+    assert host.read_vector("{0.5,2,3}") == (True, (0.5, 2, 3))
+    assert host.read_vector("<1,2,3>") == (True, (1, 2, 3))
+    assert host.read_vector("1,2,3") == (True, (1, 2, 3))
+    # VectorFunc.h:65: no sign, no exponent, no space; wrong arity; last term needs a leading digit
+    for bad in ["(-8,2,3)", "(8,2)", "(1,2,3,4)", "(1e1,2,3)", "(1, 2,3)", "(a,b,c)", "", "(1,2,.5)", "((1,2,3)"]:
+        ok, v = host.read_vector(bad)
+        assert not ok and v == (0, 0, 0), bad
+    # a negative camera coordinate therefore zeroes the vector and main() carries on (Path Tracer.cpp:147)
+    s, used_defaults = host.read_settings(REFERENCE_CONFIG.replace("(8,2,3)\t", "(-8,2,3)\t"))
+    assert not used_defaults and s["cameraPosition"] == (0, 0, 0)
+
+
+def test_image_height(kat):
+    for v in kat["image_height"]:
+        txt = REFERENCE_CONFIG.replace("= 400", "= %d" % v["width"]).replace("1.7777777777 ", "%r " % v["aspect"])
+        s, _ = host.read_settings(txt)
+        assert s["imageHeight"] == v["height"]
+
+
+def test_camera_matches_oracle_bit_for_bit(orc):
+    assert np.array_equal(host.camera_setup(), orc.camera_setup())
+    kw = dict(pos=(3, 5, 9), look=(1, 0.5, 0), up=(0, 1, 0), aspect=1.7777777777, focal=1.5, fov=40.0, aperture=0.3)
+    assert np.array_equal(host.camera_setup(**kw), orc.camera_setup(**kw))
+    g = np.load(os.path.join(GOLDEN, "camera.npy"))
+    assert np.array_equal(host.camera_setup(), g[0]) and np.array_equal(host.camera_setup(**kw), g[1])
+
+
+def test_scene_matches_golden_bit_for_bit(kat):
+    for count, a, b in [(250, 1, 2), (500, 1, 2), (250, 20260101, 77)]:
+        g = np.load(os.path.join(GOLDEN, "scene_%d_%d_%d.npz" % (count, a, b)))
+        sc = host.generate_scene(count, a, b)
+        for k in sc:
+            assert np.array_equal(sc[k], g[k]), k
+    sc = host.generate_scene(0, 1, 2)
+    for i, f in enumerate(kat["fixed_spheres"]):
+        assert [sc["cx"][i], sc["cy"][i], sc["cz"][i]] == f["c"] and sc["r"][i] == f["r"] and sc["kind"][i] == f["kind"]
+
+
+def test_scene_properties(orc):
+    sc = host.generate_scene(250, 5, 6)
+    n = len(sc["kind"])
+    assert 5 < n <= 255
+    c = np.stack([sc["cx"], sc["cy"], sc["cz"]], axis=1)
+    # no two spheres overlap (Path Tracer.cpp:222), random ones rest on y = 0 with r in [0.1, 0.4)
+    d = np.linalg.norm(c[:, None, :] - c[None, :, :], axis=2)
+    rr = sc["r"][:, None] + sc["r"][None, :]
+    iu = np.triu_indices(n, 1)
+    assert np.all(d[iu] >= rr[iu])
+    assert np.array_equal(sc["cy"][5:], sc["r"][5:]) and sc["r"][5:].min() >= 0.1 and sc["r"][5:].max() < 0.4
+    assert np.all(sc["fuzz"][5:][sc["kind"][5:] == 1] < 0.5) and np.all(sc["ior"][sc["kind"] == 2] == 1.5)
+    # crowded square: the generator stops at the first sphere that does not fit in 50 attempts (:236)
+    few = host.generate_scene(2000, 1, 2, half_extent=2.0)
+    assert len(few["kind"]) < 300
+    ofew = orc.generate_scene(2000, 1, 2, half_extent=2.0)
+    assert all(np.array_equal(few[k], ofew[k]) for k in few)
+    # config[3]-style material split
+    mix = host.generate_scene(500, 1, 2, diffuse_below=0.1, metal_below=0.5)
+    frac = [(mix["kind"][5:] == k).mean() for k in range(3)]
+    assert abs(frac[0] - 0.1) < 0.05 and abs(frac[1] - 0.4) < 0.07 and abs(frac[2] - 0.5) < 0.07
+
+
+def test_ppm_is_byte_exact(orc, kat):
+    g = np.load(os.path.join(GOLDEN, "t7_ppm.npz"))
+    ppm = host.format_ppm(g["sum"], int(g["spp"]))
+    assert ppm == g["ppm"].tobytes()
+    assert ppm == orc.format_ppm(g["sum"].astype(np.float64), int(g["spp"]))
+    vals = kat["quantise"]
+    s = np.zeros((1, len(vals), 3), dtype=np.float32)
+    for i, v in enumerate(vals):
+        s[0, i, :] = v["mean"] * 4
+    lines = host.format_ppm(s, 4).decode().split("\n")
+    assert lines[:3] == ["P3", "%d 1" % len(vals), "255"]
+    assert lines[3:3 + len(vals)] == [" ".join([str(v["value"])] * 3) for v in vals]
