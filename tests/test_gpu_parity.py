@@ -1,0 +1,404 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same inputs,
+against the committed fixtures and against the hand-derived known answers.
+
+Tolerances (BASELINE.json north_star):
+  * scene buffers: bit-exact (CPU tests: test_host.py);
+  * per-ray t, point, normal, scatter direction under injected numbers: 1e-4 relative to the double
+    path (REL below; measured errors are ~1e-6);
+  * frame under identical philox numbers: per-pixel agreement up to the few paths whose discrete
+    decisions flip in fp32; frame under different numbers: per-pixel RMSE within the expected
+    sigma at matched spp and mean luminance within 0.5 %.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def vec_rel_err(a, b):
+    """|a - b| relative to the length of b, per row."""
+    return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def scene250(orc, dev):
+    from path_tracer_amd import host
+    sc = host.generate_scene(250, 1, 2)
+    cam = host.camera_setup()
+    dev.set_scene(sc)
+    dev.set_camera(cam)
+    hs = orc.scene_create(sc)
+    yield sc, cam, hs
+    orc.scene_free(hs)
+
+
+def use(dev, sc, cam=None):
+    dev.set_scene(sc)
+    if cam is not None:
+        dev.set_camera(cam)
+
+
+def spheres(lst):
+    sc = {k: [] for k in ("cx", "cy", "cz", "r", "kind", "ar", "ag", "ab", "fuzz", "ior")}
+    for s in lst:
+        sc["cx"].append(s["c"][0]); sc["cy"].append(s["c"][1]); sc["cz"].append(s["c"][2]); sc["r"].append(s["r"])
+        sc["kind"].append(s.get("kind", 0))
+        a = s.get("albedo", (1, 1, 1))
+        sc["ar"].append(a[0]); sc["ag"].append(a[1]); sc["ab"].append(a[2])
+        sc["fuzz"].append(s.get("fuzz", 0.0)); sc["ior"].append(s.get("ior", 1.5))
+    return sc
+
+
+# ---------------------------------------------------------------------------------------------
+def test_philox_known_answers_and_oracle(dev, orc, kat):
+    ctr = np.array([v["ctr"] for v in kat["philox4x32_10"]], dtype=np.uint32)
+    for v in kat["philox4x32_10"]:
+        assert list(dev.philox([v["ctr"]], v["key"])[0]) == v["out"]
+    rng = np.random.default_rng(1)
+    ctr = rng.integers(0, 2**32, size=(4096, 4), dtype=np.uint64).astype(np.uint32)
+    key = np.array([123456789, 987654321], dtype=np.uint32)
+    out = dev.philox(ctr, key)
+    ref = np.stack([orc.philox(c, key) for c in ctr[:512]])
+    assert np.array_equal(out[:512], ref)
+
+
+def test_gen_ray_T5(dev, orc, scene250):
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    g = np.load(os.path.join(GOLDEN, "t5_gen_ray.npz"))
+    o, d = dev.gen_ray(int(g["W"]), int(g["H"]), g["pi"], g["pj"], g["u1"], g["u2"], g["diskx"], g["disky"])
+    assert vec_rel_err(o, g["o"]).max() < REL and vec_rel_err(d, g["d"]).max() < REL
+    # a non-default camera and a 4K frame, against the live oracle
+    kw = dict(pos=(3, 5, 9), look=(1, 0.5, 0), up=(0, 1, 0), aspect=1.7777777777, focal=1.5, fov=40.0, aperture=0.3)
+    cam2 = orc.camera_setup(**kw)
+    dev.set_camera(cam2)
+    rng = np.random.default_rng(5)
+    n = 4096
+    pi, pj = rng.integers(0, 3840, n), rng.integers(0, 2160, n)
+    u1, u2 = f32(rng.random(n)), f32(rng.random(n))
+    dx, dy = f32(rng.uniform(-0.7, 0.7, n)), f32(rng.uniform(-0.7, 0.7, n))
+    o, d = dev.gen_ray(3840, 2160, pi, pj, u1, u2, dx, dy)
+    oo, od = orc.gen_ray(cam2, 3840, 2160, pi, pj, u1, u2, dx, dy)
+    assert vec_rel_err(o, oo).max() < REL and vec_rel_err(d, od).max() < REL
+    dev.set_camera(cam)
+
+
+def check_scan(g, r, allow_mismatch=0):
+    mism = g["idx"] != r["idx"]
+    assert mism.sum() <= allow_mismatch, "index mismatches: %d" % mism.sum()
+    hit = ~mism & (r["idx"] >= 0)
+    assert hit.sum() > 0
+    assert (np.abs(g["t"][hit] - r["t"][hit]) / r["t"][hit]).max() < REL
+    assert vec_rel_err(g["p"][hit], r["p"][hit]).max() < REL
+    assert np.abs(g["n"][hit] - r["n"][hit]).max() < REL          # unit vectors: absolute = relative
+    assert np.array_equal(g["front"][hit], r["front"][hit])
+    return hit
+
+
+def test_scan_T3_fixture(dev, scene250):
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    g = np.load(os.path.join(GOLDEN, "t3_scan.npz"))
+    r = {k: g["r_" + k] for k in ("t", "idx", "p", "n", "front")}
+    out = dev.scan(g["o"], g["d"])
+    hit = check_scan(out, r, allow_mismatch=1)
+    assert (r["idx"][hit] == 1).sum() > 100          # plenty of ground hits (r = 1000), many of them grazing
+
+
+def test_scan_T3_live_500_spheres(dev, orc):
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    cam = host.camera_setup()
+    use(dev, sc, cam)
+    hs = orc.scene_create(sc)
+    rng = np.random.default_rng(7)
+    n = 20000
+    # rays from above the scene in random downward directions, un-normalised
+    o = f32(np.stack([rng.uniform(-10, 10, n), rng.uniform(0.5, 6, n), rng.uniform(-10, 10, n)], axis=1))
+    d = rng.normal(size=(n, 3))
+    d[:, 1] = -np.abs(d[:, 1])
+    d = f32(d * rng.uniform(0.05, 12, size=(n, 1)))
+    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=2)
+    # rays leaving the surfaces (secondary rays), starting just above the hit point
+    r0 = orc.scan(hs, o, d)
+    sel = r0["idx"] >= 0
+    p0 = f32(r0["p"][sel] + 1e-3 * r0["n"][sel])
+    d1 = f32(rng.normal(size=p0.shape))
+    check_scan(dev.scan(p0, d1), orc.scan(hs, p0, d1), allow_mismatch=2)
+    orc.scene_free(hs)
+
+
+def test_scan_kats_and_edges(dev, orc, kat):
+    for name in ("sphere_hit", "sphere_hit_inside"):
+        k = kat[name]
+        use(dev, spheres([k["sphere"]]))
+        r = dev.scan([k["ray"]["o"]], [k["ray"]["d"]])
+        assert r["idx"][0] == 0 and r["t"][0] == pytest.approx(k["t"], rel=1e-6)
+        assert np.allclose(r["p"][0], k["p"], atol=1e-5) and np.allclose(r["n"][0], k["n"], atol=1e-6)
+        assert r["front"][0] == k["front"]
+    k = kat["tie_goes_to_later_index"]
+    use(dev, spheres(k["spheres"]))
+    r = dev.scan([k["ray"]["o"]], [k["ray"]["d"]])
+    assert r["idx"][0] == k["idx"] and r["t"][0] == pytest.approx(k["t"], rel=1e-6)
+    # a miss, a sphere behind the ray, t_min cutting the near root, an empty batch
+    use(dev, spheres([{"c": [0, 0, -5], "r": 1}]))
+    r = dev.scan([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 0], [0, 0, 1], [0, 0, -1]])
+    assert list(r["idx"]) == [-1, -1, 0]
+    r = dev.scan([[0, 0, 0]], [[0, 0, -1]], t_min=5.0)          # near root 4 < t_min: far root 6
+    assert r["idx"][0] == 0 and r["t"][0] == pytest.approx(6.0, rel=1e-6) and r["front"][0] == 0
+    r = dev.scan(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert len(r["idx"]) == 0
+    # sphere counts around the pair/quad padding
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9):
+        lst = [{"c": list(rng.uniform(-3, 3, 3) + np.array([0, 0, -8])), "r": float(rng.uniform(0.3, 1.0))} for _ in range(n)]
+        sc = spheres(lst)
+        use(dev, sc)
+        hs = orc.scene_create(sc)
+        o = np.zeros((512, 3))
+        d = f32(np.stack([rng.uniform(-0.6, 0.6, 512), rng.uniform(-0.6, 0.6, 512), -np.ones(512)], axis=1))
+        check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=1)
+        orc.scene_free(hs)
+
+
+def test_scatter_T4_fixture(dev):
+    g = np.load(os.path.join(GOLDEN, "t4_scatter.npz"))
+    s = dev.scatter(g["kind"], g["albedo"], g["fuzz"], g["ior"], g["d_in"], g["p"], g["nrm"], g["front"], g["u"])
+    assert np.array_equal(s["ok"], g["r_ok"])
+    assert vec_rel_err(s["d"], g["r_d"]).max() < REL
+    assert np.abs(s["atten"] - g["r_atten"]).max() < 1e-7
+    for kind in (0, 1, 2):
+        assert (g["kind"] == kind).sum() > 100
+
+
+def test_scatter_kats(dev, kat):
+    k = kat["lambertian"]
+    s = dev.scatter([0], [k["albedo"]], [0.0], [0.0], [[0, -1, 0]], [[0, 0, 0]], [k["n"]], [1], [k["u"]])
+    assert np.allclose(s["d"][0], k["d_out"], atol=1e-6) and np.allclose(s["atten"][0], k["atten"], atol=1e-7) and s["ok"][0] == 1
+    k = kat["metal_mirror"]
+    s = dev.scatter([1], [k["albedo"]], [k["fuzz"]], [0.0], [k["d_in"]], [[0, 0, 0]], [k["n"]], [1], [k["u"]])
+    assert np.allclose(s["d"][0], k["d_out"], atol=1e-6) and s["ok"][0] == 1
+    for name in ("dielectric_quirk", "dielectric_reflect_by_coin"):
+        k = kat[name]
+        s = dev.scatter([2], [[1, 1, 1]], [0.0], [k["ior"]], [k["d_in"]], [[0, 0, 0]], [k["n"]], [k["front"]], [[0, 0, k["u3"]]])
+        assert np.allclose(s["d"][0], k["d_out"], atol=1e-6) and s["ok"][0] == 1 and np.allclose(s["atten"][0], [1, 1, 1])
+    for v in kat["sphere_point"]:
+        s = dev.scatter([1], [[1, 1, 1]], [1.0], [0.0], [[0, -1, 0]], [[0, 0, 0]], [[0, 1, 0]], [1], [[v["u1"], v["u2"], 0]])
+        assert np.allclose(s["d"][0] - np.array([0, 1, 0]), v["v"], atol=2e-6)
+    # a metal hit at exact grazing: refl.n = 0 is not > 0, the scatter is refused (Metal.cpp:14)
+    s = dev.scatter([1], [[1, 1, 1]], [0.0], [0.0], [[1, 0, 0]], [[0, 0, 0]], [[0, 1, 0]], [1], [[0.1, 0.2, 0]])
+    assert s["ok"][0] == 0
+
+
+def test_scatter_dielectric_regimes(dev, orc):
+    """Total internal reflection, the un-normalised-cosine quirk and Schlick, against the oracle."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3))
+    d -= nrm * np.maximum(0, (d * nrm).sum(1, keepdims=True)) * 2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d *= rng.choice([0.05, 0.5, 1.0, 2.0, 9.0], size=(n, 1))
+    d, nrm = f32(d), f32(nrm)
+    keep = (d * nrm).sum(1) < -1e-3
+    d, nrm = d[keep], nrm[keep]
+    n = len(d)
+    front = rng.integers(0, 2, n)
+    u = f32(rng.random((n, 3)))
+    kind = np.full(n, 2)
+    args = (kind, np.ones((n, 3)), np.zeros(n), np.full(n, 1.5), d, np.zeros((n, 3)), nrm, front, u)
+    g, r = dev.scatter(*args), orc.scatter(*args)
+    # a coin that lands within fp32 rounding of the reflectance may flip: allow a handful
+    same = vec_rel_err(g["d"], r["d"]) < REL
+    assert (~same).sum() <= 3, (~same).sum()
+    assert np.all(g["ok"] == 1)
+
+
+def test_sky(dev, orc, kat):
+    for v in kat["sky"]:
+        assert np.allclose(dev.sky([v["d"]])[0], v["rgb"], atol=1e-6)
+    rng = np.random.default_rng(2)
+    d = f32(rng.normal(size=(2048, 3)) * 5)
+    assert np.abs(dev.sky(d) - orc.sky(d)).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+def frame_vs_oracle(dev, orc, sc, cam, W, H, spp, depth, key0=1, key1=2, frac_tol=0.02):
+    use(dev, sc, cam)
+    hs = orc.scene_create(sc)
+    img, rays = dev.render_image(W, H, spp, depth, seed=(key1 << 32) | key0)
+    ref, _, ref_rays = orc.render(hs, cam, W, H, 0, spp, depth, mode=1, seed_a=key0, seed_b=key1, threads=os.cpu_count() or 1)
+    orc.scene_free(hs)
+    diff = np.abs(img.astype(np.float64) - ref).max(axis=2) / spp
+    return img, ref, rays, ref_rays, float((diff > 2e-3).mean()), float(np.median(diff))
+
+
+def test_frame_same_numbers_as_oracle(dev, orc, scene250):
+    """T6, strongest form: the oracle draws the same philox numbers, so every path should match
+    until an fp32 rounding flips a discrete decision."""
+    sc, cam, hs = scene250
+    img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 96, 54, 8, 50)
+    assert med < 2e-6 and frac_off < 0.02, (med, frac_off)
+    assert abs(img.mean() - ref.mean()) < 0.002 * ref.mean()
+    assert abs(rays - ref_rays) < 0.005 * ref_rays
+    g = np.load(os.path.join(GOLDEN, "t6b_philox_96x54.npz"))
+    d = np.abs(img.astype(np.float64) - g["sum"]).max(axis=2) / 8
+    assert (d > 2e-3).mean() < 0.02 and abs(rays - int(g["rays"])) < 0.005 * int(g["rays"])
+
+
+def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
+    """400x225-like odd sizes (partial tiles) and the dielectric/metal-heavy scene of configs[3]."""
+    from path_tracer_amd import host
+    cam = host.camera_setup(aspect=101 / 57)
+    sc = host.generate_scene(250, 3, 4, diffuse_below=0.1, metal_below=0.5)
+    img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 101, 57, 4, 100, key0=7, key1=9)
+    assert med < 5e-6 and frac_off < 0.05, (med, frac_off)
+    assert abs(img.mean() - ref.mean()) < 0.005 * ref.mean() and abs(rays - ref_rays) < 0.01 * ref_rays
+
+
+def test_frame_statistics_T6(dev, scene250):
+    """T6 as BASELINE states it: against the converged render made with the reference's Mersenne-Twister
+    streams (fixture), per-pixel RMSE within the expected sigma at matched spp, mean luminance within 0.5 %."""
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    g = np.load(os.path.join(GOLDEN, "t6_image_160x90.npz"))
+    spp = 256
+    img, rays = dev.render_image(160, 90, spp, 50, seed=2026)
+    mean = img.astype(np.float64) / spp
+    lum_gpu, lum_ref = mean.mean(), g["mean"].astype(np.float64).mean()
+    assert abs(lum_gpu - lum_ref) < 0.005 * lum_ref, (lum_gpu, lum_ref)
+    var = g["var"].astype(np.float64) * (1.0 / spp + 1.0 / int(g["spp"]))     # expected variance of the difference
+    chi = ((mean - g["mean"]) ** 2).sum() / var.sum()
+    assert 0.85 < chi < 1.15, chi
+    rmse = np.sqrt(((mean - g["mean"]) ** 2).mean())
+    sigma = np.sqrt(var.mean())
+    assert rmse <= 1.1 * sigma, (rmse, sigma)
+    assert abs(rays / (160 * 90 * spp) - float(g["rays_per_sample"])) < 0.01 * float(g["rays_per_sample"])
+
+
+def test_depth_zero_empty_range_and_errors(dev, scene250):
+    from path_tracer_amd import Device, PtError
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    img, rays = dev.render_image(40, 23, 3, 0)            # Path Tracer.cpp:86
+    assert rays == 0 and not img.any()
+    dev.clear_accum(40, 23)
+    assert dev.render(40, 23, 5, 5, 50, 1, want_rays=True) == 0
+    assert not dev.read_accum(40, 23).any()
+    img, rays = dev.render_image(40, 23, 2, 1)            # depth 1: exactly one ray per sample
+    assert rays == 40 * 23 * 2
+    with pytest.raises(PtError):
+        dev.render(0, 10, 0, 1, 5, 1)
+    with pytest.raises(PtError):
+        dev.render(10, 10, 3, 1, 5, 1)
+    with pytest.raises(PtError):
+        dev.render(10, 10, 0, 1, -1, 1)
+    fresh = Device(0)
+    with pytest.raises(PtError, match="scene"):
+        fresh.render(8, 8, 0, 1, 5, 1)
+    with pytest.raises(PtError):
+        fresh.set_scene(dict(cx=[0], cy=[0], cz=[0], r=[-1.0], kind=[0], ar=[1], ag=[1], ab=[1], fuzz=[0], ior=[1.5]))
+    with pytest.raises(PtError):
+        fresh.set_scene(dict(cx=[0], cy=[0], cz=[0], r=[1.0], kind=[7], ar=[1], ag=[1], ab=[1], fuzz=[0], ior=[1.5]))
+    fresh.close()
+
+
+def test_determinism_linearity_and_split(dev, scene250):
+    """Size-independent properties: the same call twice is bit-identical (integer sums), a sample
+    range is the sum of its parts, the job split does not change the frame."""
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    W, H = 200, 113
+    a, ra = dev.render_image(W, H, 12, 50, seed=99)
+    b, rb = dev.render_image(W, H, 12, 50, seed=99)
+    assert ra == rb and np.array_equal(a, b)
+    dev.clear_accum(W, H)
+    r1 = dev.render(W, H, 0, 5, 50, 99, want_rays=True)
+    r2 = dev.render(W, H, 5, 12, 50, 99, want_rays=True)
+    c = dev.read_accum(W, H)
+    assert r1 + r2 == ra
+    assert np.abs(c - a).max() <= 4e-6 * max(1.0, float(a.max()))
+    d, _ = dev.render_image(W, H, 12, 50, seed=100)
+    assert not np.array_equal(a, d) and abs(float(a.mean()) - float(d.mean())) < 0.02 * float(a.mean())
+    # samples [12, 24) are new samples, not a repeat of [0, 12)
+    e, _ = dev.render_image(W, H, 12, 50, seed=99, spp_begin=12)
+    assert not np.array_equal(a, e)
+
+
+def test_external_accumulation_buffer(dev, scene250):
+    import torch
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    W, H = 64, 36
+    own, rays = dev.render_image(W, H, 4, 50, seed=5)
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev.render(W, H, 0, 4, 50, 5, accum_ptr=buf.data_ptr())
+    dev.render(W, H, 0, 4, 50, 5, accum_ptr=buf.data_ptr())      # adds: twice the frame
+    torch.cuda.synchronize()
+    dev.set_stream(0)
+    assert np.allclose(buf.cpu().numpy(), 2 * own, rtol=1e-6, atol=1e-6)
+    kt = dev.kernel_times()
+    assert len(kt) >= 2 and np.all(kt > 0)
+
+
+def test_full_size_properties(dev, orc):
+    """configs[1] at full size: 1920x1080, 505 spheres, maxDepth 50 (fewer spp than the bench, the
+    properties do not depend on it): ray count, luminance, black-free sky band, repeatability."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    cam = host.camera_setup()
+    use(dev, sc, cam)
+    W, H, spp = 1920, 1080, 8
+    img, rays = dev.render_image(W, H, spp, 50, seed=42)
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= spp * 1.0001
+    rps = rays / (W * H * spp)
+    assert 2.3 < rps < 3.0
+    # low-resolution oracle of the same scene and camera: same mean luminance and rays per sample
+    hs = orc.scene_create(sc)
+    ref, _, ref_rays = orc.render(hs, cam, 240, 135, 0, 16, 50, mode=1, seed_a=1, seed_b=2, threads=os.cpu_count() or 1)
+    orc.scene_free(hs)
+    assert abs(img.mean() / spp - ref.mean() / 16) < 0.01 * ref.mean() / 16
+    assert abs(rps - ref_rays / (240 * 135 * 16)) < 0.02 * rps
+    # block averages of the full frame against the oracle's low-resolution frame
+    blk = img.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3)) / spp
+    assert np.abs(blk - ref / 16).mean() < 0.03
+    img2, rays2 = dev.render_image(W, H, spp, 50, seed=42)
+    assert rays2 == rays and np.array_equal(img, img2)
+
+
+def test_large_scene_10k_spheres(dev, orc):
+    """configs[4]: 10,000 random spheres on a half extent of 45; scan and a small frame."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(10000, 1, 2, half_extent=45.0)
+    assert len(sc["kind"]) > 9000
+    cam = host.camera_setup()
+    use(dev, sc, cam)
+    hs = orc.scene_create(sc)
+    rng = np.random.default_rng(4)
+    n = 4000
+    o = f32(np.stack([rng.uniform(-40, 40, n), rng.uniform(0.5, 4, n), rng.uniform(-40, 40, n)], axis=1))
+    d = rng.normal(size=(n, 3)); d[:, 1] = -np.abs(d[:, 1]) * 0.3
+    d = f32(d)
+    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=2)
+    img, rays = dev.render_image(64, 36, 2, 50, seed=(2 << 32) | 1)
+    ref, _, ref_rays = orc.render(hs, cam, 64, 36, 0, 2, 50, mode=1, seed_a=1, seed_b=2, threads=os.cpu_count() or 1)
+    orc.scene_free(hs)
+    diff = np.abs(img - ref).max(axis=2) / 2
+    assert (diff > 2e-3).mean() < 0.03 and abs(rays - ref_rays) < 0.01 * ref_rays
