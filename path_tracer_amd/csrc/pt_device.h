@@ -181,7 +181,7 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
 
 // ---------------------------------------------------------------------------------------------
 // Finish: the hit record of the winning sphere in fp64 (Sphere.cpp:6-30, Hittable.h:26-31).
-// t is returned in unit-direction units; the reference's t is t / len.
+// t and tmin are in unit-direction units; the reference's t is t / len.
 // ---------------------------------------------------------------------------------------------
 struct HitRec {
     f3 p, n;
@@ -189,7 +189,7 @@ struct HitRec {
     double t_unit;
     double px, py, pz, nx, ny, nz;   // the same point and normal before rounding to fp32
 };
-PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, float len) {
+PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, double tmin) {
     const GeomRec g = sc.geom[idx];
     const double ox = o.x, oy = o.y, oz = o.z, dx = dh.x, dy = dh.y, dz = dh.z;
     const double ocx = ox - g.cx, ocy = oy - g.cy, ocz = oz - g.cz;            // Sphere.cpp:6
@@ -202,7 +202,6 @@ PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, fl
     const double inv_a = 2.0 - a;        // 1/a to 4e-14 since |a - 1| <= 2e-7
     const double t1 = (-hb - sq) * inv_a;                                        // :17
     const double t2 = (-hb + sq) * inv_a;                                        // :19
-    const double tmin = 0.001 * double(len);
     const double t = (self || t1 < tmin) ? t2 : t1;                              // :18
     HitRec h;
     h.t_unit = t;

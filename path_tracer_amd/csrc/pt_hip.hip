@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
                 atomicAdd(&acc[slot * 3 + 2], to_fx(c.z));
                 active = false;
             } else {
-                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, len);
+                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
                 const MatRec m = P.scene.mat[bi];
                 const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce) + 1u, 0u, P.key0, P.key1);
                 f3 d, atten;
@@ -182,7 +182,7 @@ __global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, dou
         for (int c = 0; c < 3; ++c) { p[3 * k + c] = 0; nrm[3 * k + c] = 0; }
         return;
     }
-    const HitRec h = finish_hit(sc, bi, false, ro, dh, len);
+    const HitRec h = finish_hit(sc, bi, false, ro, dh, t_min * double(len));
     t[k] = h.t_unit / double(len);
     p[3 * k] = h.px; p[3 * k + 1] = h.py; p[3 * k + 2] = h.pz;
     nrm[3 * k] = h.nx; nrm[3 * k + 1] = h.ny; nrm[3 * k + 2] = h.nz;
