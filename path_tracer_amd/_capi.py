@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "lib", "libpt_hip.so")   # PT_HIP_LIB: diagnostic builds
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

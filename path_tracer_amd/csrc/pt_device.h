@@ -24,6 +24,10 @@
 
 #define PT_DEV __device__ __forceinline__
 
+#ifdef PT_STATS
+extern __device__ unsigned long long g_stats[8];
+#endif
+
 namespace ptd {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -124,7 +128,7 @@ PT_DEV f3 sky(float dy) {
 // Tier 2 for one flagged sphere: Sphere.cpp:16-23 and HittableList.cpp:28-31 in unit-direction t.
 // ---------------------------------------------------------------------------------------------
 PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, int& best_i) {
-    float s = fast_sqrt(__builtin_fmaxf(T, 0.0f));
+    float s = fast_sqrt(T);                                       // NaN for T < 0: every compare below is then false
     float t1 = b - s, t2 = b + s;
     float t = (t1 >= tmin) ? t1 : t2;                              // Sphere.cpp:17-19
     bool ok = (T >= 0.0f) & (j != prev) & (t >= tmin) & (t <= best_t);   // :13, :20; <= : later index wins ties
@@ -133,9 +137,9 @@ PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, 
 }
 
 // The linear scan. o, dh: ray origin and unit direction; tmin in unit-direction units
-// (0.001 * len); prev: sphere the ray starts on, or -1. Returns the approximate t and the index
-// of the closest hit (-1: miss).
-PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, float& best_t, int& best_i) {
+// (0.001 * len); prev: sphere the ray starts on, or -1; self_t: the far root of that sphere
+// (self_far_root below). Returns the approximate t and the index of the closest hit (-1: miss).
+PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
     const float nod = -dot(o, dh);
     const float noo = -dot(o, o);
     const f3 o2 = o * 2.0f;
@@ -159,24 +163,35 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
             T[h] = __builtin_elementwise_fma(b, b, e);
         }
         float m = __builtin_fmaxf(__builtin_fmaxf(T[0].x, T[0].y), __builtin_fmaxf(T[1].x, T[1].y));
-        if (m >= 0.0f) {
+#ifdef PT_STATS
+        if (threadIdx.x == 0) atomicAdd(&g_stats[2], 1ull);
+        if (__any(m >= 0.0f) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
+        { unsigned long long bm = __ballot(m >= 0.0f); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
+#endif
+        if (__any(m >= 0.0f)) {                 // wave-uniform: some lane's line meets a sphere of this quad
             const int j = 2 * q;
-            tier2(T[0].x, B[0].x, j + 0, prev, tmin, best_t, best_i);
-            tier2(T[0].y, B[0].y, j + 1, prev, tmin, best_t, best_i);
-            tier2(T[1].x, B[1].x, j + 2, prev, tmin, best_t, best_i);
-            tier2(T[1].y, B[1].y, j + 3, prev, tmin, best_t, best_i);
+            // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
+            if (__any(T[0].x >= 0.0f)) tier2(T[0].x, B[0].x, j + 0, prev, tmin, best_t, best_i);
+            if (__any(T[0].y >= 0.0f)) tier2(T[0].y, B[0].y, j + 1, prev, tmin, best_t, best_i);
+            if (__any(T[1].x >= 0.0f)) tier2(T[1].x, B[1].x, j + 2, prev, tmin, best_t, best_i);
+            if (__any(T[1].y >= 0.0f)) tier2(T[1].y, B[1].y, j + 3, prev, tmin, best_t, best_i);
         }
     }
     // The sphere the ray starts on: the near root is the start point (rejected by t_min in the
-    // reference), the far root is 2b and counts only when the ray heads into the sphere.
-    if (prev >= 0) {
-        const float* rec = sc.scan + 8 * (prev >> 1) + (prev & 1);
-        f3 c = mk3(rec[0], rec[2], rec[4]);
-        float t = 2.0f * dot(c - o, dh);
-        bool ok = (t >= tmin) & (t <= best_t);
-        best_t = ok ? t : best_t;
+    // reference), the far root counts only when the ray heads into the sphere.
+    {
+        bool ok = (prev >= 0) & (self_t >= tmin) & (self_t <= best_t);
+        best_t = ok ? self_t : best_t;
         best_i = ok ? prev : best_i;
     }
+}
+
+// Far root of the sphere a scattered ray starts on. The start point p lies on it, so
+// c - p = -r * n_out with n_out = front ? n : -n, and the roots of the unit-direction quadratic
+// are 0 and 2 (c - p).dh = -+ 2 r (n.dh).
+PT_DEV float self_far_root(float r, f3 n, bool front, f3 dh_new) {
+    const float nd = dot(n, dh_new);
+    return (front ? -2.0f : 2.0f) * r * nd;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -186,6 +201,7 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
 struct HitRec {
     f3 p, n;
     bool front;
+    float r;                         // radius of the sphere hit
     double t_unit;
     double px, py, pz, nx, ny, nz;   // the same point and normal before rounding to fp32
 };
@@ -205,6 +221,7 @@ PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, do
     const double t = (self || t1 < tmin) ? t2 : t1;                              // :18
     HitRec h;
     h.t_unit = t;
+    h.r = float(g.r);
     h.px = ox + t * dx; h.py = oy + t * dy; h.pz = oz + t * dz;                  // :27, Ray.cpp:12-14
     double nx = (h.px - g.cx) * g.inv_r, ny = (h.py - g.cy) * g.inv_r, nz = (h.pz - g.cz) * g.inv_r;   // :28
     h.front = (dx * nx + dy * ny + dz * nz) < 0.0;                               // Hittable.h:28

@@ -51,6 +51,14 @@ PT_DEV unsigned long long to_fx(float v) {
     return (unsigned long long)(v * 4294967296.0f);
 }
 
+#ifdef PT_STATS
+// Diagnostic build only (tools/stats.sh): wave-level counts of where the instruction stream goes.
+__device__ unsigned long long g_stats[8];
+#define PT_STAT_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define PT_STAT_ADD(i, v) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[64 * 3];
     const int lane = threadIdx.x;
@@ -69,6 +77,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
     // path state
     f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(1, 1, 1);
     float len = 1.0f;
+    float self_t = 0.0f;
     int slot = 0, bounce = 0, prev = -1;
     uint32_t pixel = 0, sample = 0;
 
@@ -109,12 +118,15 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
             }
         }
         if (!__any(active)) break;
+        { const int live = __popcll(__ballot(active)); (void)live;
+          PT_STAT_ADD(0, 1);                                 // wave-level ray segments
+          PT_STAT_ADD(1, live); }                            // live lanes in them
 
         // ---- one ray of every live path ----
         if (active) {
             ++rays;
             float bt; int bi;
-            scan_spheres(P.scene, o, dh, 0.001f * len, prev, bt, bi);
+            scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 atomicAdd(&acc[slot * 3 + 0], to_fx(c.x));
@@ -130,6 +142,7 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
                 thr = thr * atten;                                                   // Path Tracer.cpp:97
                 o = h.p;
                 dh = normalise(d, len);
+                self_t = self_far_root(h.r, h.n, h.front, dh);
                 prev = bi;
                 ++bounce;
                 active = ok && bounce < P.max_depth;                                 // :100, :86 -> black
@@ -175,7 +188,7 @@ __global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, dou
     float len;
     const f3 dh = normalise(rd, len);
     float bt; int bi;
-    scan_spheres(sc, ro, dh, float(t_min) * len, -1, bt, bi);
+    scan_spheres(sc, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
     idx[k] = bi;
     if (bi < 0) {
         t[k] = 0; front[k] = 0;
@@ -518,6 +531,17 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_elems, h->d_counters, h->d_counters + 1);
         PT_HIP(h, hipGetLastError());
     }
+#ifdef PT_STATS
+    {
+        unsigned long long st[8];
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        PT_HIP(h, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stats), sizeof(st)));
+        fprintf(stderr, "[pt stats] wave_segments %llu live_lanes %llu (%.3f of 64) quads %llu tier2_quads %llu (%.4f) tier2_lanes %llu\n",
+                st[0], st[1], st[0] ? double(st[1]) / st[0] / 64 : 0.0, st[2], st[3], st[2] ? double(st[3]) / st[2] : 0.0, st[4]);
+        unsigned long long z[8] = {0};
+        PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)));
+    }
+#endif
     if (ray_count_out) {
         unsigned long long v = 0;
         PT_HIP(h, hipMemcpyAsync(&v, h->d_counters, sizeof(v), hipMemcpyDeviceToHost, h->stream));
