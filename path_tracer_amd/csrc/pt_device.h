@@ -145,7 +145,10 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     const f3 o2 = o * 2.0f;
     best_t = __builtin_inff();
     best_i = -1;
-    const v2f* __restrict__ S = reinterpret_cast<const v2f*>(sc.scan);
+    // Constant address space: the scan records never change during a launch, and saying so keeps the
+    // loads scalar (s_load_dwordx16 = four spheres) even with atomics elsewhere in the kernel.
+    typedef __attribute__((address_space(4))) const v2f* scan_ptr;
+    const scan_ptr S = (scan_ptr)(unsigned long long)(sc.scan);
     const int npairs = sc.n_pad >> 1;
     for (int q = 0; q < npairs; q += 2) {
         v2f B[2], T[2];

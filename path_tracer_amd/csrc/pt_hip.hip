@@ -1,11 +1,11 @@
 // pt_hip.hip — kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h).
 //
 // Kernels
-//   k_render   the sample loop: per-lane iterative bounce loop with path regeneration. One wave
-//              (one 64-thread workgroup) takes a job = an 8x8 pixel tile x a chunk of samples and
-//              hands (pixel, sample) items to its lanes as their paths end, so every lane stays
-//              inside the sphere scan. Replaces process_row / sumColour / calcColour
-//              (Path Tracer.cpp:296-300, :265-278, :82-108).
+//   k_render   the sample loop: per-lane iterative bounce loop with path regeneration, persistent
+//              waves. A wave (one 64-thread workgroup) pulls jobs = an 8x8 pixel tile x a chunk of
+//              samples from a global counter and hands (pixel, sample) items to its lanes as their
+//              paths end, so every lane stays inside the sphere scan. Replaces process_row /
+//              sumColour / calcColour (Path Tracer.cpp:296-300, :265-278, :82-108).
 //   k_resolve  converts the job sums (64-bit fixed point, order-independent) to float and adds
 //              them into the caller's accumulation buffer.
 //   k_scan / k_scatter / k_gen_ray / k_sky / k_philox   the same device functions, one thread
@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +35,7 @@ struct RenderParams {
     int W, H;
     int spp_begin, spp_end, spp_chunk, n_chunks;
     int tiles_x;
+    int n_jobs;
     int max_depth;
     uint32_t key0, key1;
     float inv_w1, inv_h1;
@@ -41,6 +43,7 @@ struct RenderParams {
     SceneDev scene;
     unsigned long long* accum_fx;    // [H][W][3] fixed-point (2^-32) sums, top row first
     unsigned long long* ray_count;   // rays of this call
+    unsigned int* job_counter;       // next job to hand out, zero at launch
 };
 
 // Radiance in [0, 1] per channel (every attenuation and the sky are <= 1) to unsigned Q32.32.
@@ -59,65 +62,100 @@ __device__ unsigned long long g_stats[8];
 #define PT_STAT_ADD(i, v) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(64) k_render(const RenderParams P) {
-    __shared__ unsigned long long acc[64 * 3];
-    const int lane = threadIdx.x;
-    const int job = blockIdx.x;
-    const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
-    const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const int s0 = P.spp_begin + chunk * P.spp_chunk;
-    const int s1 = min(s0 + P.spp_chunk, P.spp_end);
-    const int total = 64 * (s1 - s0);        // items of this job: (sample, slot)
-    acc[lane * 3 + 0] = 0; acc[lane * 3 + 1] = 0; acc[lane * 3 + 2] = 0;
+// Adds one LDS bank of job sums to the frame and clears it. Lane l owns pixel slot l of the tile.
+PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, int ty, int lane) {
+    const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+    if (px < P.W && py < P.H) {
+        unsigned long long* dst = P.accum_fx + (size_t(py) * size_t(P.W) + size_t(px)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long v = bank[lane * 3 + c];
+            if (v) atomicAdd(dst + c, v);
+        }
+    }
+    bank[lane * 3 + 0] = 0; bank[lane * 3 + 1] = 0; bank[lane * 3 + 2] = 0;
+}
 
-    int next = 0;                            // wave-uniform: first item not handed out yet
-    bool active = false, exhausted = false;
+// Persistent waves. Each wave pulls jobs (8x8 tile x sample chunk) from a global counter and hands
+// the job's (sample, pixel-slot) items to its lanes as their paths end. When a job's items run out
+// the wave moves straight on to the next job while the last paths of the previous one are still in
+// flight (two LDS banks of sums, flushed when drained), so lanes idle only at the very end of the frame.
+__global__ void __launch_bounds__(64) k_render(const RenderParams P) {
+    __shared__ unsigned long long acc[2 * 192];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[lane + 64 * i] = 0;
+
+    // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining
+    int parity = 0;
+    int c_tx = 0, c_ty = 0, c_s0 = 0, c_total = 0, c_next = 0;
+    int o_tx = 0, o_ty = 0;
+    bool c_valid = false, o_valid = false, no_more_jobs = false;
+
+    bool active = false;
     unsigned int rays = 0;
 
     // path state
     f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(1, 1, 1);
     float len = 1.0f;
     float self_t = 0.0f;
-    int slot = 0, bounce = 0, prev = -1;
+    int slot = 0, bounce = 0, prev = -1, lbank = 0;
     uint32_t pixel = 0, sample = 0;
 
     for (;;) {
         // ---- hand new items to the lanes whose path has ended (regeneration) ----
-        bool need = !active && !exhausted;
+        bool need = !active;
         while (__any(need)) {
+            if (c_next >= c_total) {                         // wave-uniform: the current job is handed out
+                if (no_more_jobs) break;
+                if (__any(active && lbank != parity)) break; // the other bank is still draining: wait for it
+                if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
+                int job = 0;
+                if (lane == 0) job = int(atomicAdd(P.job_counter, 1u));
+                job = __builtin_amdgcn_readfirstlane(job);
+                if (job >= P.n_jobs) { no_more_jobs = true; break; }
+                o_tx = c_tx; o_ty = c_ty; o_valid = c_valid;
+                parity ^= 1;
+                const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
+                c_ty = tile / P.tiles_x; c_tx = tile - c_ty * P.tiles_x;
+                c_s0 = P.spp_begin + chunk * P.spp_chunk;
+                c_total = 64 * (min(c_s0 + P.spp_chunk, P.spp_end) - c_s0);
+                c_next = 0;
+                c_valid = true;
+                continue;
+            }
             const unsigned long long m = __ballot(need);
             const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0));
-            const int k = next + rank;
-            next += __popcll(m);
-            if (need) {
-                if (k >= total) {
-                    exhausted = true;
-                    need = false;
-                } else {
-                    slot = k & 63;
-                    const int px = tx * 8 + (slot & 7), py = ty * 8 + (slot >> 3);   // py from the top
-                    if (px < P.W && py < P.H) {
-                        const int j = P.H - 1 - py;                                  // Path Tracer.cpp:298
-                        pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
-                        sample = uint32_t(s0 + (k >> 6));
-                        const u4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
-                        // jitter, then a polar map of two uniforms onto the unit disk (same distribution
-                        // as the rejection loop of VectorFunc.cpp:57-64)
-                        const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
-                        f3 d;
-                        gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang),
-                                rad * sin_rev(ang), o, d);
-                        dh = normalise(d, len);
-                        thr = mk3(1, 1, 1);
-                        bounce = 0;
-                        prev = -1;
-                        active = P.max_depth > 0;                                    // Path Tracer.cpp:86
-                        need = !active;
-                    }
+            const int k = c_next + rank;
+            c_next += __popcll(m);
+            if (need && k < c_total) {
+                slot = k & 63;
+                const int px = c_tx * 8 + (slot & 7), py = c_ty * 8 + (slot >> 3);   // py from the top
+                if (px < P.W && py < P.H) {
+                    const int j = P.H - 1 - py;                                      // Path Tracer.cpp:298
+                    pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
+                    sample = uint32_t(c_s0 + (k >> 6));
+                    const u4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
+                    // jitter, then a polar map of two uniforms onto the unit disk (same distribution
+                    // as the rejection loop of VectorFunc.cpp:57-64)
+                    const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
+                    f3 d;
+                    gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang),
+                            rad * sin_rev(ang), o, d);
+                    dh = normalise(d, len);
+                    thr = mk3(1, 1, 1);
+                    bounce = 0;
+                    prev = -1;
+                    lbank = parity;
+                    active = P.max_depth > 0;                                        // Path Tracer.cpp:86
+                    need = !active;
                 }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (no_more_jobs) break;
+            continue;
+        }
         { const int live = __popcll(__ballot(active)); (void)live;
           PT_STAT_ADD(0, 1);                                 // wave-level ray segments
           PT_STAT_ADD(1, live); }                            // live lanes in them
@@ -129,9 +167,10 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
             scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
-                atomicAdd(&acc[slot * 3 + 0], to_fx(c.x));
-                atomicAdd(&acc[slot * 3 + 1], to_fx(c.y));
-                atomicAdd(&acc[slot * 3 + 2], to_fx(c.z));
+                unsigned long long* a = acc + 192 * lbank + slot * 3;
+                atomicAdd(a + 0, to_fx(c.x));
+                atomicAdd(a + 1, to_fx(c.y));
+                atomicAdd(a + 2, to_fx(c.z));
                 active = false;
             } else {
                 const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
@@ -150,20 +189,13 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
         }
     }
 
-    // ---- job sums to the frame ----
-    {
-        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-        if (px < P.W && py < P.H) {
-            unsigned long long* dst = P.accum_fx + (size_t(py) * size_t(P.W) + size_t(px)) * 3;
-            atomicAdd(dst + 0, acc[lane * 3 + 0]);
-            atomicAdd(dst + 1, acc[lane * 3 + 1]);
-            atomicAdd(dst + 2, acc[lane * 3 + 2]);
-        }
-        unsigned int r = rays;
+    // ---- the last sums to the frame ----
+    if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
+    if (c_valid) flush_bank(P, acc + 192 * parity, c_tx, c_ty, lane);
+    unsigned int r = rays;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
-        if (lane == 0) atomicAdd(P.ray_count, (unsigned long long)r);
-    }
+    for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
+    if (lane == 0 && r) atomicAdd(P.ray_count, (unsigned long long)r);
 }
 
 __global__ void k_resolve(unsigned long long* fx, float* out, size_t n, const unsigned long long* call_rays,
@@ -273,11 +305,13 @@ struct pt_context {
     size_t fx_elems = 0;
     float* d_accum = nullptr;
     int acc_w = 0, acc_h = 0;
-    unsigned long long* d_counters = nullptr;   // [0] rays of the current call, [1] rays since creation
+    unsigned long long* d_counters = nullptr;   // [0] rays of the current call, [1] job counter, [2] rays since creation
+    int resident_waves = 0;                     // waves the device holds at once (persistent grid size)
     // kernel timing
     std::vector<hipEvent_t> ev;                 // pairs
     size_t ev_used = 0;
-    int target_jobs = 65536;
+    int target_jobs = 262144;
+    int grid_factor_pct = 100;                  // PT_GRID_PCT: persistent grid as a percentage of the resident waves
 };
 
 static thread_local std::string g_create_err;
@@ -340,10 +374,11 @@ int pt_create(int device_index, pt_handle* out) {
     e = hipStreamCreate(&h->own_stream);
     if (e != hipSuccess) { delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 2 * sizeof(unsigned long long));
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long));
     if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
+    if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
     *out = h;
     return 0;
 }
@@ -491,7 +526,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         PT_HIP(h, hipMemsetAsync(h->d_fx, 0, n_elems * sizeof(unsigned long long), h->stream));
         h->fx_elems = n_elems;
     }
-    PT_HIP(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long), h->stream));
+    PT_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     const int spp = spp_end - spp_begin;
     if (spp > 0) {
         RenderParams P;
@@ -515,6 +550,16 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         P.scene = scene_dev(h);
         P.accum_fx = h->d_fx;
         P.ray_count = h->d_counters;
+        P.job_counter = reinterpret_cast<unsigned int*>(h->d_counters + 1);
+        P.n_jobs = int(jobs);
+        if (h->resident_waves <= 0) {
+            int per_cu = 0;
+            PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, 64, 0));
+            hipDeviceProp_t prop;
+            PT_HIP(h, hipGetDeviceProperties(&prop, h->device));
+            h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
+        }
+        const long long grid = std::min<long long>(jobs, (long long)h->resident_waves * h->grid_factor_pct / 100);
         const bool timed = h->ev_used + 2 <= 8192;
         if (timed && h->ev.size() < h->ev_used + 2) {
             hipEvent_t a, b;
@@ -522,13 +567,13 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
             h->ev.push_back(a); h->ev.push_back(b);
         }
         if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-        hipLaunchKernelGGL(k_render, dim3(unsigned(jobs)), dim3(64), 0, h->stream, P);
+        hipLaunchKernelGGL(k_render, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
         PT_HIP(h, hipGetLastError());
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     }
     {
         const unsigned blocks = unsigned(std::min<size_t>((n_elems + 255) / 256, 256 * 16));
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_elems, h->d_counters, h->d_counters + 1);
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_elems, h->d_counters, h->d_counters + 2);
         PT_HIP(h, hipGetLastError());
     }
 #ifdef PT_STATS
@@ -555,7 +600,7 @@ int pt_ray_count(pt_handle h, uint64_t* out) {
     if (!h || !out) return PT_ERR_INVALID;
     PT_HIP(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    PT_HIP(h, hipMemcpyAsync(&v, h->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipMemcpyAsync(&v, h->d_counters + 2, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     *out = v;
     return 0;
