@@ -8,7 +8,8 @@
 // The closest-hit search (HittableList.cpp:21-36 over Sphere.cpp:5-23) is split in three:
 //   tier 1  every sphere, packed fp32 FMA on sphere PAIRS held in scalar registers:
 //           T = ((c-o).dh)^2 - |c-o|^2 + r^2, written so that the sphere data only multiplies
-//           per-ray constants:  b = c.dh - o.dh,  T = b*b + 2 o.c - |o|^2 - K,  K = |c|^2 - r^2;
+//           per-ray constants:  b = c.dh - o.dh,  T = b*b - K + 2 o.c - |o|^2,  K = |c|^2 - r^2
+//           (seven packed FMAs per pair; the per-ray |o|^2 is left to the compare);
 //           T >= 0  <=>  the ray's line meets the sphere (disc >= 0 at Sphere.cpp:10-13);
 //   tier 2  only for the spheres some lane flagged: roots b -+ sqrt(T), the reference's root
 //           choice and range test (Sphere.cpp:16-23), closest-so-far update with ties to the
@@ -141,7 +142,7 @@ PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, 
 // (self_far_root below). Returns the approximate t and the index of the closest hit (-1: miss).
 PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
     const float nod = -dot(o, dh);
-    const float noo = -dot(o, o);
+    const float oo = dot(o, o);
     const f3 o2 = o * 2.0f;
     best_t = __builtin_inff();
     best_i = -1;
@@ -151,33 +152,35 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     const scan_ptr S = (scan_ptr)(unsigned long long)(sc.scan);
     const int npairs = sc.n_pad >> 1;
     for (int q = 0; q < npairs; q += 2) {
-        v2f B[2], T[2];
+        // Seven packed FMAs per sphere pair, each with exactly one scalar operand:
+        //   b = c.dh - o.dh;  U = b*b - K + 2 o.c  ( = T + |o|^2 );  the line meets the sphere iff U >= |o|^2.
+        v2f B[2], U[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const v2f cx = S[4 * (q + h) + 0], cy = S[4 * (q + h) + 1], cz = S[4 * (q + h) + 2], K = S[4 * (q + h) + 3];
             v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{nod, nod});
             b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
             b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
-            v2f e = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, v2f{noo, noo});
-            e = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, e);
-            e = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, e);
-            e = e - K;
+            v2f u = __builtin_elementwise_fma(b, b, -K);
+            u = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, u);
+            u = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, u);
+            u = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, u);
             B[h] = b;
-            T[h] = __builtin_elementwise_fma(b, b, e);
+            U[h] = u;
         }
-        float m = __builtin_fmaxf(__builtin_fmaxf(T[0].x, T[0].y), __builtin_fmaxf(T[1].x, T[1].y));
+        const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
 #ifdef PT_STATS
         if (threadIdx.x == 0) atomicAdd(&g_stats[2], 1ull);
-        if (__any(m >= 0.0f) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
-        { unsigned long long bm = __ballot(m >= 0.0f); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
+        if (__any(m >= oo) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
+        { unsigned long long bm = __ballot(m >= oo); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
 #endif
-        if (__any(m >= 0.0f)) {                 // wave-uniform: some lane's line meets a sphere of this quad
+        if (__any(m >= oo)) {                   // wave-uniform: some lane's line meets a sphere of this quad
             const int j = 2 * q;
             // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
-            if (__any(T[0].x >= 0.0f)) tier2(T[0].x, B[0].x, j + 0, prev, tmin, best_t, best_i);
-            if (__any(T[0].y >= 0.0f)) tier2(T[0].y, B[0].y, j + 1, prev, tmin, best_t, best_i);
-            if (__any(T[1].x >= 0.0f)) tier2(T[1].x, B[1].x, j + 2, prev, tmin, best_t, best_i);
-            if (__any(T[1].y >= 0.0f)) tier2(T[1].y, B[1].y, j + 3, prev, tmin, best_t, best_i);
+            if (__any(U[0].x >= oo)) tier2(U[0].x - oo, B[0].x, j + 0, prev, tmin, best_t, best_i);
+            if (__any(U[0].y >= oo)) tier2(U[0].y - oo, B[0].y, j + 1, prev, tmin, best_t, best_i);
+            if (__any(U[1].x >= oo)) tier2(U[1].x - oo, B[1].x, j + 2, prev, tmin, best_t, best_i);
+            if (__any(U[1].y >= oo)) tier2(U[1].y - oo, B[1].y, j + 3, prev, tmin, best_t, best_i);
         }
     }
     // The sphere the ray starts on: the near root is the start point (rejected by t_min in the
