@@ -102,9 +102,38 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
     int slot = 0, bounce = 0, prev = -1, lbank = 0;
     uint32_t pixel = 0, sample = 0;
 
+    // One iteration = one ray of every live path: scan, then either the sky (path ends) or the hit
+    // record; lanes whose path ended take a new (sample, pixel) item; ONE philox block per lane then
+    // feeds either the camera ray of a new path (bounce 0) or the scatter of a continuing one.
     for (;;) {
+        HitRec h;
+        MatRec mat;
+        bool hit = false;
+        if (active) {
+            ++rays;
+            float bt; int bi;
+            scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
+                const f3 c = thr * sky(dh.y);
+                unsigned long long* a = acc + 192 * lbank + slot * 3;
+                atomicAdd(a + 0, to_fx(c.x));
+                atomicAdd(a + 1, to_fx(c.y));
+                atomicAdd(a + 2, to_fx(c.z));
+                active = false;
+            } else {
+                h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
+                mat = P.scene.mat[bi];
+                prev = bi;
+                ++bounce;
+                // the next ray would enter calcColour with depth <= 0: black whatever the scatter (Path Tracer.cpp:86)
+                hit = active = bounce < P.max_depth;
+            }
+        }
+
         // ---- hand new items to the lanes whose path has ended (regeneration) ----
         bool need = !active;
+        bool fresh = false;
+        int px = 0, j = 0;
         while (__any(need)) {
             if (c_next >= c_total) {                         // wave-uniform: the current job is handed out
                 if (no_more_jobs) break;
@@ -129,26 +158,19 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
             const int k = c_next + rank;
             c_next += __popcll(m);
             if (need && k < c_total) {
-                slot = k & 63;
-                const int px = c_tx * 8 + (slot & 7), py = c_ty * 8 + (slot >> 3);   // py from the top
-                if (px < P.W && py < P.H) {
-                    const int j = P.H - 1 - py;                                      // Path Tracer.cpp:298
+                const int s = k & 63;
+                const int x = c_tx * 8 + (s & 7), py = c_ty * 8 + (s >> 3);          // py from the top
+                if (x < P.W && py < P.H && P.max_depth > 0) {                        // Path Tracer.cpp:86
+                    slot = s;
+                    px = x;
+                    j = P.H - 1 - py;                                                // Path Tracer.cpp:298
                     pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
                     sample = uint32_t(c_s0 + (k >> 6));
-                    const u4 r = philox4x32_10(pixel, sample, 0u, 0u, P.key0, P.key1);
-                    // jitter, then a polar map of two uniforms onto the unit disk (same distribution
-                    // as the rejection loop of VectorFunc.cpp:57-64)
-                    const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
-                    f3 d;
-                    gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang),
-                            rad * sin_rev(ang), o, d);
-                    dh = normalise(d, len);
-                    thr = mk3(1, 1, 1);
                     bounce = 0;
                     prev = -1;
                     lbank = parity;
-                    active = P.max_depth > 0;                                        // Path Tracer.cpp:86
-                    need = !active;
+                    fresh = active = true;
+                    need = false;
                 }
             }
         }
@@ -160,31 +182,26 @@ __global__ void __launch_bounds__(64) k_render(const RenderParams P) {
           PT_STAT_ADD(0, 1);                                 // wave-level ray segments
           PT_STAT_ADD(1, live); }                            // live lanes in them
 
-        // ---- one ray of every live path ----
+        // ---- the next ray of every live path ----
         if (active) {
-            ++rays;
-            float bt; int bi;
-            scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
-                const f3 c = thr * sky(dh.y);
-                unsigned long long* a = acc + 192 * lbank + slot * 3;
-                atomicAdd(a + 0, to_fx(c.x));
-                atomicAdd(a + 1, to_fx(c.y));
-                atomicAdd(a + 2, to_fx(c.z));
-                active = false;
-            } else {
-                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
-                const MatRec m = P.scene.mat[bi];
-                const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce) + 1u, 0u, P.key0, P.key1);
-                f3 d, atten;
-                const bool ok = shade(m, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
+            const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, P.key0, P.key1);
+            f3 d;
+            if (fresh) {
+                // jitter, then a polar map of two uniforms onto the unit disk (same distribution as
+                // the rejection loop of VectorFunc.cpp:57-64)
+                const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
+                gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang), rad * sin_rev(ang), o, d);
+                thr = mk3(1, 1, 1);
+                dh = normalise(d, len);
+            }
+            if (hit) {
+                f3 atten;
+                const bool ok = shade(mat, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
                 thr = thr * atten;                                                   // Path Tracer.cpp:97
                 o = h.p;
                 dh = normalise(d, len);
                 self_t = self_far_root(h.r, h.n, h.front, dh);
-                prev = bi;
-                ++bounce;
-                active = ok && bounce < P.max_depth;                                 // :100, :86 -> black
+                active = ok;                                                         // Path Tracer.cpp:100 -> black
             }
         }
     }
