@@ -250,7 +250,7 @@ PT_DEV bool shade(const MatRec& m, f3 dh, float len, f3 n, bool front, float u1,
 
     // Lambertian.cpp:7-10
     f3 lam = n + S;
-    lam = (dot(lam, lam) <= 1e-30f) ? n : lam;
+    lam = select3(dot(lam, lam) <= 1e-30f, n, lam);
     // Metal.cpp:10, :14
     const f3 met = fma3(S, m.fuzz, refl);
     const bool met_ok = dot(refl, n) > 0.0f;

@@ -80,7 +80,10 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 // the job's (sample, pixel-slot) items to its lanes as their paths end. When a job's items run out
 // the wave moves straight on to the next job while the last paths of the previous one are still in
 // flight (two LDS banks of sums, flushed when drained), so lanes idle only at the very end of the frame.
-__global__ void __launch_bounds__(64) k_render(const RenderParams P) {
+#ifndef PT_WAVES_PER_EU
+#define PT_WAVES_PER_EU 6
+#endif
+__global__ void __launch_bounds__(64, PT_WAVES_PER_EU) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[2 * 192];
     const int lane = threadIdx.x;
 #pragma unroll

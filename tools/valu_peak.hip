@@ -16,7 +16,7 @@
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-constexpr int ITERS = 1 << 16;
+constexpr int ITERS = 1 << 14;
 constexpr int ILP = 16;
 
 #define KERNEL_HEAD(name)                                                                     \
@@ -52,6 +52,22 @@ KERNEL_HEAD(k_pk_vvv)    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc2[
 KERNEL_HEAD(k_pk_svv)    asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc2[i]) : "s"(va), "v"(vb)); KERNEL_TAIL
 KERNEL_HEAD(k_pk_mul_sv) asm volatile("v_pk_mul_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
 KERNEL_HEAD(k_pk_add_sv) asm volatile("v_pk_add_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
+// other instructions of the sample loop (issue cost only; operands are whatever the registers hold)
+KERNEL_HEAD(k_max_vv)    asm volatile("v_max_f32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_max3_vvv)  asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));  KERNEL_TAIL
+KERNEL_HEAD(k_cmp_vv)    asm volatile("v_cmp_ge_f32 vcc, %0, %1" : "+v"(acc[i]) : "v"(b) : "vcc");   KERNEL_TAIL
+KERNEL_HEAD(k_cndmask)   asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(b) : "vcc"); KERNEL_TAIL
+KERNEL_HEAD(k_xor)       asm volatile("v_xor_b32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_sqrt)      asm volatile("v_sqrt_f32 %0, %0"        : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_rsq)       asm volatile("v_rsq_f32 %0, %0"         : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_sin)       asm volatile("v_sin_f32 %0, %0"         : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_mul_lo)    asm volatile("v_mul_lo_u32 %0, %0, %1"  : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_mul_hi)    asm volatile("v_mul_hi_u32 %0, %0, %1"  : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_mad_u64)   asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(acc2[i]) : "v"(a), "v"(b) : "vcc"); KERNEL_TAIL
+KERNEL_HEAD(k_fma_f64)   asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(acc2[i]));                   KERNEL_TAIL
+KERNEL_HEAD(k_add_f64)   asm volatile("v_add_f64 %0, %0, %0"     : "+v"(acc2[i]));                   KERNEL_TAIL
+KERNEL_HEAD(k_cvt_f64)   asm volatile("v_cvt_f64_f32 %0, %1"     : "+v"(acc2[i]) : "v"(b));          KERNEL_TAIL
+KERNEL_HEAD(k_rsq_f64)   asm volatile("v_rsq_f64 %0, %0"         : "+v"(acc2[i]));                   KERNEL_TAIL
 
 typedef void (*kern_t)(float*, unsigned long long*, float, float);
 struct Form { const char* name; kern_t k; int flops_per_lane; };
@@ -68,10 +84,14 @@ int main() {
         {"v_fmac_f32 v,v", k_fmac_vv, 2}, {"v_mul_f32 s,v", k_mul_sv, 1}, {"v_sub_f32 s,v", k_sub_sv, 1},
         {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4},
         {"v_pk_mul_f32 s,v", k_pk_mul_sv, 2}, {"v_pk_add_f32 s,v", k_pk_add_sv, 2},
+        {"v_max_f32 v,v", k_max_vv, 1}, {"v_max3_f32 v,v,v", k_max3_vvv, 1}, {"v_cmp_ge_f32 v,v", k_cmp_vv, 1},
+        {"v_cndmask_b32", k_cndmask, 1}, {"v_xor_b32", k_xor, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1},
+        {"v_sin_f32", k_sin, 1}, {"v_mul_lo_u32", k_mul_lo, 1}, {"v_mul_hi_u32", k_mul_hi, 1}, {"v_mad_u64_u32", k_mad_u64, 1},
+        {"v_fma_f64", k_fma_f64, 2}, {"v_add_f64", k_add_f64, 1}, {"v_cvt_f64_f32", k_cvt_f64, 1}, {"v_rsq_f64", k_rsq_f64, 1},
     };
-    printf("%-20s %-6s %-9s %-9s %-14s %-9s\n", "form", "w/SIMD", "ms", "TFLOP/s", "cyc/inst/SIMD", "clock GHz");
+    printf("%-20s %-6s %-9s %-9s %-12s\n", "form", "w/SIMD", "ms", "TFLOP/s", "Ginst/s/SIMD");
     for (const Form& f : forms) {
-        for (int k = 1; k <= 8; k *= 2) {           // k blocks of 256 threads per CU = k waves per SIMD
+        for (int k = 2; k <= 8; k *= 4) {           // k blocks of 256 threads per CU = k waves per SIMD
             int grid = cus * k;
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             hipLaunchKernelGGL(f.k, dim3(grid), dim3(256), 0, 0, out, cyc, 0.999f, 0.001f);
@@ -86,8 +106,10 @@ int main() {
             double inst = double(ITERS) * ILP;                  // per wave
             double cyc_per_inst_simd = med_cyc / (inst * k);    // k waves share a SIMD
             double flops = double(grid) * 256 * inst * f.flops_per_lane;
-            printf("%-20s %-6d %-9.3f %-9.2f %-14.3f %-9.3f\n", f.name, k, ms, flops / ms / 1e9, cyc_per_inst_simd,
-                   med_cyc / (ms * 1e6));
+            (void)cyc_per_inst_simd;
+            // wave-instructions per second per SIMD: the issue rate that matters for a VALU-bound kernel
+            printf("%-20s %-6d %-9.3f %-9.2f %-12.3f\n", f.name, k, ms, flops / ms / 1e9,
+                   double(grid) * 4 * inst / (ms * 1e-3) / (cus * 4.0) / 1e9);
             CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
         }
     }
