@@ -62,7 +62,7 @@ struct SceneDev {
     const GeomRec* geom;   // n
     const MatRec* mat;     // n
     int n;                 // spheres in list order
-    int n_pad;             // multiple of 4; the padding never hits
+    int n_pad;             // multiple of 4; the padding never hits; one more never-hit quad follows it
 };
 struct CameraDev {         // Camera.cpp:27-31, as floats; ll_rel = lowerLeft - position
     f3 pos, ll_rel, hor, ver, u, v;

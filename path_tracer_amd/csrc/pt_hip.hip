@@ -445,10 +445,10 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     const int n_pad = (n + 3) & ~3;
-    std::vector<float> scan(size_t(n_pad) * 4);
+    std::vector<float> scan(size_t(n_pad + 4) * 4);    // + one quad that the pipelined loads may touch
     std::vector<GeomRec> geom(n);
     std::vector<MatRec> mat(n);
-    for (int i = 0; i < n_pad; ++i) {
+    for (int i = 0; i < n_pad + 4; ++i) {
         float* rec = scan.data() + 8 * (i >> 1) + (i & 1);
         if (i < n) {
             rec[0] = float(cx[i]); rec[2] = float(cy[i]); rec[4] = float(cz[i]);
@@ -557,6 +557,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         long long want = (h->target_jobs + tiles - 1) / tiles;
         if (want < 1) want = 1;
         if (want > spp) want = spp;
+        if (want > (spp + 3) / 4) want = (spp + 3) / 4;     // at least 4 spp (256 items) per job
         P.spp_chunk = int((spp + want - 1) / want);
         P.n_chunks = (spp + P.spp_chunk - 1) / P.spp_chunk;
         const long long jobs = tiles * P.n_chunks;
