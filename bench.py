@@ -55,6 +55,24 @@ def cpu_baseline(n_spheres_random, threads):
                       % (w, h, spp, n_spheres_random + 5, threads, dt)}
 
 
+def measured_traffic(default_workload):
+    """HBM bytes per k_render launch from the newest committed rocprofv3 counter summary (profiles/*_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH doubled as the gfx950 correction). Only
+    valid for the default workload, on which it was measured; the kernel is VALU-bound and these bytes are the
+    fixed-point job sums (atomics) plus a few KB of scene data."""
+    if not default_workload:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["k_render_hbm_bytes_per_launch"]["total"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +177,8 @@ def main():
             "rays_per_s": total_rays / dt,
             "rays_per_sample": total_rays / samples,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": measured_traffic((W, H, spp, depth, args.spheres) == (1920, 1080, 100, 50, 500)),
                          "kernel": "k_render", "kernel_ms": k_ms,
                          "flops_per_launch": flops_per_launch,
                          "note": "algorithmic flops = rays x (17 x spheres + 60); rays counted by the kernel"},

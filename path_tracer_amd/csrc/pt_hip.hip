@@ -41,7 +41,7 @@ struct RenderParams {
     float inv_w1, inv_h1;
     CameraDev cam;
     SceneDev scene;
-    unsigned long long* accum_fx;    // [H][W][3] fixed-point (2^-32) sums, top row first
+    unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
     unsigned long long* ray_count;   // rays of this call
     unsigned int* job_counter;       // next job to hand out, zero at launch
 };
@@ -66,11 +66,13 @@ __device__ unsigned long long g_stats[8];
 PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, int ty, int lane) {
     const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
     if (px < P.W && py < P.H) {
-        unsigned long long* dst = P.accum_fx + (size_t(py) * size_t(P.W) + size_t(px)) * 3;
+        // planar sums: the 8 lanes of a tile row add to 64 contiguous bytes
+        const size_t plane = size_t(P.W) * size_t(P.H);
+        unsigned long long* dst = P.accum_fx + size_t(py) * size_t(P.W) + size_t(px);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const unsigned long long v = bank[lane * 3 + c];
-            if (v) atomicAdd(dst + c, v);
+            if (v) atomicAdd(dst + c * plane, v);
         }
     }
     bank[lane * 3 + 0] = 0; bank[lane * 3 + 1] = 0; bank[lane * 3 + 2] = 0;
@@ -218,14 +220,17 @@ __global__ void __launch_bounds__(64, PT_WAVES_PER_EU) k_render(const RenderPara
     if (lane == 0 && r) atomicAdd(P.ray_count, (unsigned long long)r);
 }
 
-__global__ void k_resolve(unsigned long long* fx, float* out, size_t n, const unsigned long long* call_rays,
+__global__ void k_resolve(unsigned long long* fx, float* out, size_t n_pixels, const unsigned long long* call_rays,
                           unsigned long long* total_rays) {
     const size_t stride = size_t(gridDim.x) * blockDim.x;
-    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const unsigned long long v = fx[i];
-        if (v) {
-            out[i] += float(double(v) * (1.0 / 4294967296.0));
-            fx[i] = 0;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels; i += stride) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long v = fx[c * n_pixels + i];
+            if (v) {
+                out[3 * i + c] += float(double(v) * (1.0 / 4294967296.0));
+                fx[c * n_pixels + i] = 0;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *total_rays += *call_rays;
@@ -593,8 +598,9 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     }
     {
-        const unsigned blocks = unsigned(std::min<size_t>((n_elems + 255) / 256, 256 * 16));
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_elems, h->d_counters, h->d_counters + 2);
+        const size_t n_pixels = n_elems / 3;
+        const unsigned blocks = unsigned(std::min<size_t>((n_pixels + 255) / 256, 256 * 16));
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_pixels, h->d_counters, h->d_counters + 2);
         PT_HIP(h, hipGetLastError());
     }
 #ifdef PT_STATS
