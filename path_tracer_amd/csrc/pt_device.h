@@ -58,11 +58,11 @@ struct MatRec {           // 32 bytes, two float4 loads
     int kind;
 };
 struct SceneDev {
-    const float* scan;     // n_pad/2 pair records of 8 floats: cx0,cx1, cy0,cy1, cz0,cz1, K0,K1
+    const float* scan;     // n_pad/2 pair records of 8 floats: cx0,cx1, cy0,cy1, cz0,cz1, -K0,-K1  (K = |c|^2 - r^2)
     const GeomRec* geom;   // n
     const MatRec* mat;     // n
     int n;                 // spheres in list order
-    int n_pad;             // multiple of 4; the padding never hits; one more never-hit quad follows it
+    int n_pad;             // multiple of 4; the padding never hits; two more never-hit quads follow it
 };
 struct CameraDev {         // Camera.cpp:27-31, as floats; ll_rel = lowerLeft - position
     f3 pos, ll_rel, hor, ver, u, v;
@@ -129,12 +129,59 @@ PT_DEV f3 sky(float dy) {
 // Tier 2 for one flagged sphere: Sphere.cpp:16-23 and HittableList.cpp:28-31 in unit-direction t.
 // ---------------------------------------------------------------------------------------------
 PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, int& best_i) {
+    asm volatile("" : "+s"(j));   // keep j a scalar register: hipcc otherwise rewrites `j != prev` into a vector add per quad in tier 1
     float s = fast_sqrt(T);                                       // NaN for T < 0: every compare below is then false
     float t1 = b - s, t2 = b + s;
     float t = (t1 >= tmin) ? t1 : t2;                              // Sphere.cpp:17-19
     bool ok = (T >= 0.0f) & (j != prev) & (t >= tmin) & (t <= best_t);   // :13, :20; <= : later index wins ties
     best_t = ok ? t : best_t;
     best_i = ok ? j : best_i;
+}
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// One s_load_dwordx16. The destination counts as written when the statement ends although the data
+// arrives later: swait() on the same value must come before its first use.
+PT_DEV v16f sload16(const float* p) {
+    v16f r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p));
+    return r;
+}
+PT_DEV void swait(v16f& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+
+// Tier 1 and, when flagged, tier 2 for the four spheres of one record quad R (spheres j .. j+3).
+PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float nod, f3 o2, float oo, int prev, float tmin, float& best_t,
+                      int& best_i) {
+    // Seven packed FMAs per sphere pair, each with exactly one scalar operand:
+    //   b = c.dh - o.dh;  U = b*b + (-K) + 2 o.c  ( = T + |o|^2 );  the line meets the sphere iff U >= |o|^2.
+    v2f B[2], U[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const v2f cx = v2f{R[8 * h + 0], R[8 * h + 1]}, cy = v2f{R[8 * h + 2], R[8 * h + 3]};
+        const v2f cz = v2f{R[8 * h + 4], R[8 * h + 5]}, nK = v2f{R[8 * h + 6], R[8 * h + 7]};   // nK = r^2 - |c|^2
+        v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{nod, nod});
+        b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
+        b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
+        v2f u = __builtin_elementwise_fma(b, b, nK);
+        u = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, u);
+        u = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, u);
+        u = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, u);
+        B[h] = b;
+        U[h] = u;
+    }
+    const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
+#ifdef PT_STATS
+    if (threadIdx.x == 0) atomicAdd(&g_stats[2], 1ull);
+    if (__any(m >= oo) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
+    { unsigned long long bm = __ballot(m >= oo); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
+#endif
+    if (__any(m >= oo)) {                       // wave-uniform: some lane's line meets a sphere of this quad
+        // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
+        if (__any(U[0].x >= oo)) tier2(U[0].x - oo, B[0].x, j + 0, prev, tmin, best_t, best_i);
+        if (__any(U[0].y >= oo)) tier2(U[0].y - oo, B[0].y, j + 1, prev, tmin, best_t, best_i);
+        if (__any(U[1].x >= oo)) tier2(U[1].x - oo, B[1].x, j + 2, prev, tmin, best_t, best_i);
+        if (__any(U[1].y >= oo)) tier2(U[1].y - oo, B[1].y, j + 3, prev, tmin, best_t, best_i);
+    }
 }
 
 // The linear scan. o, dh: ray origin and unit direction; tmin in unit-direction units
@@ -146,43 +193,25 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     const f3 o2 = o * 2.0f;
     best_t = __builtin_inff();
     best_i = -1;
-    // Constant address space: the scan records never change during a launch, and saying so keeps the
-    // loads scalar (s_load_dwordx16 = four spheres) even with atomics elsewhere in the kernel.
-    typedef __attribute__((address_space(4))) const v2f* scan_ptr;
-    const scan_ptr S = (scan_ptr)(unsigned long long)(sc.scan);
-    const int npairs = sc.n_pad >> 1;
-    for (int q = 0; q < npairs; q += 2) {
-        // Seven packed FMAs per sphere pair, each with exactly one scalar operand:
-        //   b = c.dh - o.dh;  U = b*b - K + 2 o.c  ( = T + |o|^2 );  the line meets the sphere iff U >= |o|^2.
-        v2f B[2], U[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const v2f cx = S[4 * (q + h) + 0], cy = S[4 * (q + h) + 1], cz = S[4 * (q + h) + 2], K = S[4 * (q + h) + 3];
-            v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{nod, nod});
-            b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
-            b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
-            v2f u = __builtin_elementwise_fma(b, b, -K);
-            u = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, u);
-            u = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, u);
-            u = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, u);
-            B[h] = b;
-            U[h] = u;
-        }
-        const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
-#ifdef PT_STATS
-        if (threadIdx.x == 0) atomicAdd(&g_stats[2], 1ull);
-        if (__any(m >= oo) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
-        { unsigned long long bm = __ballot(m >= oo); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
-#endif
-        if (__any(m >= oo)) {                   // wave-uniform: some lane's line meets a sphere of this quad
-            const int j = 2 * q;
-            // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
-            if (__any(U[0].x >= oo)) tier2(U[0].x - oo, B[0].x, j + 0, prev, tmin, best_t, best_i);
-            if (__any(U[0].y >= oo)) tier2(U[0].y - oo, B[0].y, j + 1, prev, tmin, best_t, best_i);
-            if (__any(U[1].x >= oo)) tier2(U[1].x - oo, B[1].x, j + 2, prev, tmin, best_t, best_i);
-            if (__any(U[1].y >= oo)) tier2(U[1].y - oo, B[1].y, j + 3, prev, tmin, best_t, best_i);
-        }
+    // The scan records come through the scalar cache, one s_load_dwordx16 (four spheres) at a time, in two
+    // register banks: the request for the next quad is issued right after the wait that delivers the
+    // current one, so it is in flight for the whole of the current quad's arithmetic. (hipcc emits the
+    // load next to its first use, which exposes the scalar-cache miss latency once the scene outgrows
+    // that cache; the loads and their waits are therefore written out. SMEM returns out of order, so
+    // the only usable wait is lgkmcnt(0), placed BEFORE the next request.)
+    const float* rec = sc.scan;
+    const int n_pad = sc.n_pad;                  // multiple of 4: the host pads, and two more never-hit quads follow
+    v16f bankA = sload16(rec);
+    for (int j = 0; j < n_pad; j += 8) {
+        swait(bankA);
+        v16f bankB = sload16(rec + 16);
+        scan_quad(bankA, j, dh, nod, o2, oo, prev, tmin, best_t, best_i);
+        swait(bankB);
+        bankA = sload16(rec + 32);
+        if (j + 4 < n_pad) scan_quad(bankB, j + 4, dh, nod, o2, oo, prev, tmin, best_t, best_i);
+        rec += 32;
     }
+    swait(bankA);                                // the last request (never-hit padding) must land before the registers are reused
     // The sphere the ray starts on: the near root is the start point (rejected by t_min in the
     // reference), the far root counts only when the ray heads into the sphere.
     {

@@ -450,20 +450,20 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     const int n_pad = (n + 3) & ~3;
-    std::vector<float> scan(size_t(n_pad + 4) * 4);    // + one quad that the pipelined loads may touch
+    std::vector<float> scan(size_t(n_pad + 8) * 4);    // + two quads that the pipelined loads may touch
     std::vector<GeomRec> geom(n);
     std::vector<MatRec> mat(n);
-    for (int i = 0; i < n_pad + 4; ++i) {
+    for (int i = 0; i < n_pad + 8; ++i) {
         float* rec = scan.data() + 8 * (i >> 1) + (i & 1);
         if (i < n) {
             rec[0] = float(cx[i]); rec[2] = float(cy[i]); rec[4] = float(cz[i]);
-            // K from the float centre the scan multiplies with, so that b*b + 2 o.c - |o|^2 - K is
+            // -K from the float centre the scan multiplies with, so that b*b + 2 o.c - |o|^2 - K is
             // the discriminant of the sphere tier 1 actually sees; r^2 in double.
             const double fx = rec[0], fy = rec[2], fz = rec[4];
-            rec[6] = float(fx * fx + fy * fy + fz * fz - r[i] * r[i]);
+            rec[6] = float(r[i] * r[i] - (fx * fx + fy * fy + fz * fz));   // -K
         } else {
             rec[0] = rec[2] = rec[4] = 0.0f;
-            rec[6] = 1e30f;                      // never flagged
+            rec[6] = -1e30f;                     // -K: never flagged
         }
     }
     for (int i = 0; i < n; ++i) {
