@@ -40,8 +40,8 @@ def cpu_baseline(n_spheres_random, threads):
     orc.render(hs, cam, w, h, 0, spp, 50, mode=0, seed_a=11, seed_b=12, threads=threads, shared_b=1)
     dt = time.time() - t0
     total = w * h * spp
-    # extend towards ~12 s of CPU work, at most 4 spp
-    more = int(min(3, max(0, 12.0 / max(dt, 1e-3) - 1)))
+    # extend towards ~12 s of CPU work, at most 16 spp
+    more = int(min(15, max(0, 12.0 / max(dt, 1e-3) - 1)))
     if more > 0:
         t1 = time.time()
         orc.render(hs, cam, w, h, spp, spp + more, 50, mode=0, seed_a=11, seed_b=12, threads=threads, shared_b=1)
