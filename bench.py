@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--spheres", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank control flow on ONE device: every rank renders on cuda:0 and the reduce goes "
+                         "through gloo on host copies (RCCL refuses two ranks on one GPU); not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -100,8 +103,10 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the sample loop has no CPU path", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    ptd.init("nccl")          # RCCL; a single process needs no group
+    ptd.init("gloo" if args.rehearse_on_one_gpu else "nccl")   # "nccl" is RCCL; a single process needs no group
 
     from path_tracer_amd import Device, host
 
@@ -119,7 +124,12 @@ def main():
     def step():
         accum.zero_()
         dev.render(W, H, spp_begin, spp_end, depth, 42, accum_ptr=accum.data_ptr())
-        ptd.reduce_frame(accum, dst=0)
+        if args.rehearse_on_one_gpu and world > 1:
+            host_copy = accum.cpu()
+            ptd.reduce_frame(host_copy, dst=0)
+            accum.copy_(host_copy)
+        else:
+            ptd.reduce_frame(accum, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,10 +152,11 @@ def main():
     ktimes = dev.kernel_times()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        stat_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        r = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        r = torch.tensor([rays], dtype=torch.int64, device=stat_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays = int(r.item())
     else:
