@@ -82,6 +82,17 @@ int pt_clear_accum(pt_handle h, int width, int height);
 int pt_read_accum(pt_handle h, float* host_f32);   /* replaces reading `pixels` at Path Tracer.cpp:320 */
 void* pt_accum_device_ptr(pt_handle h);
 
+/* Upload a saved accumulation buffer (width*height*3 floats, top row first) into the handle's own
+ * buffer, so that a frame can be resumed: write, then pt_render() further sample ranges. The reference
+ * keeps its image in memory until the end (Path Tracer.cpp:292-293, :316) and cannot resume. */
+int pt_write_accum(pt_handle h, int width, int height, const float* host_f32);
+
+/* The output stage on the device: gamma, clamp and quantise (writeColour, Path Tracer.cpp:62-74) of
+ * the sums over `spp` samples in accum_rgb_f32 (DEVICE buffer; NULL = the handle's own), in the
+ * reference's double arithmetic, into width*height*3 bytes at host_rgb8 (top row first, r g b).
+ * The bytes are the numbers the reference prints into its P3 file. Synchronises. */
+int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* accum_rgb_f32, uint8_t* host_rgb8);
+
 /* Rays traced since the handle was created (synchronises). */
 int pt_ray_count(pt_handle h, uint64_t* out);
 

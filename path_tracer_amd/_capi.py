@@ -29,6 +29,8 @@ SIGNATURES = {
     "pt_clear_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pt_read_accum": (C.c_int, [C.c_void_p, _fp]),
     "pt_accum_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "pt_write_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
+    "pt_quantise_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8)]),
     "pt_ray_count": (C.c_int, [C.c_void_p, _u64p]),
     "pt_kernel_times": (C.c_int, [C.c_void_p, _fp, C.c_int, _ip]),
     "pt_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
@@ -142,6 +144,18 @@ class Device:
     def read_accum(self, width, height):
         out = np.zeros((height, width, 3), dtype=np.float32)
         self._ck(self.lib.pt_read_accum(self.h, _p(out, _fp)), "pt_read_accum")
+        return out
+
+    def write_accum(self, sums):
+        """Upload saved sums (H, W, 3 float32) into the handle's own buffer, to resume a frame."""
+        a = np.ascontiguousarray(sums, dtype=np.float32)
+        self._ck(self.lib.pt_write_accum(self.h, a.shape[1], a.shape[0], _p(a, _fp)), "pt_write_accum")
+
+    def quantise_rgb8(self, width, height, spp, accum_ptr=None):
+        """Gamma, clamp, quantise on the device (writeColour): returns uint8 (H, W, 3)."""
+        out = np.zeros((height, width, 3), dtype=np.uint8)
+        self._ck(self.lib.pt_quantise_rgb8(self.h, width, height, spp, C.c_void_p(accum_ptr) if accum_ptr else None,
+                                           out.ctypes.data_as(C.POINTER(C.c_uint8))), "pt_quantise_rgb8")
         return out
 
     def render_image(self, width, height, spp, max_depth=50, seed=42, spp_begin=0):

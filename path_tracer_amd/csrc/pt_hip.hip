@@ -236,6 +236,16 @@ __global__ void k_resolve(unsigned long long* fx, float* out, size_t n_pixels, c
     if (blockIdx.x == 0 && threadIdx.x == 0) *total_rays += *call_rays;
 }
 
+// writeColour (Path Tracer.cpp:62-74) per channel, in double like the reference.
+__global__ void k_quantise(const float* sum, size_t n, double scale, unsigned char* out) {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = __builtin_sqrt(scale * double(sum[i]));         // :69-71
+        v = v < 0.0 ? 0.0 : (v > 0.999 ? 0.999 : v);               // std::clamp(v, 0.0, 0.999), :73
+        out[i] = (unsigned char)(int)(256.0 * v);
+    }
+}
+
 __global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, double t_min, double* t, int* idx,
                        double* p, double* nrm, int* front) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,6 +533,36 @@ int pt_read_accum(pt_handle h, float* host_f32) {
     if (!h->d_accum) return fail(h, PT_ERR_STATE, "pt_read_accum: no accumulation buffer (call pt_clear_accum or pt_render first)");
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipMemcpyAsync(host_f32, h->d_accum, size_t(h->acc_w) * h->acc_h * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_write_accum(pt_handle h, int width, int height, const float* host_f32) {
+    if (!h || !host_f32) return PT_ERR_INVALID;
+    int rc = pt_clear_accum(h, width, height);
+    if (rc) return rc;
+    PT_HIP(h, hipMemcpyAsync(h->d_accum, host_f32, size_t(width) * height * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* accum_rgb_f32, uint8_t* host_rgb8) {
+    if (!h || !host_rgb8) return PT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || spp <= 0 || size_t(width) * size_t(height) > (size_t(1) << 28))
+        return fail(h, PT_ERR_INVALID, "pt_quantise_rgb8: bad size or sample count");
+    const float* src = accum_rgb_f32;
+    if (!src) {
+        if (!h->d_accum || h->acc_w != width || h->acc_h != height) return fail(h, PT_ERR_STATE, "pt_quantise_rgb8: the handle has no accumulation buffer of this size");
+        src = h->d_accum;
+    }
+    PT_HIP(h, hipSetDevice(h->device));
+    const size_t n = size_t(width) * height * 3;
+    DevBuf out;
+    PT_HIP(h, out.alloc(n));
+    const unsigned blocks = unsigned(std::min<size_t>((n + 255) / 256, 256 * 16));
+    hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, h->stream, src, n, 1.0 / double(spp), out.as<unsigned char>());
+    PT_HIP(h, hipGetLastError());
+    PT_HIP(h, hipMemcpyAsync(host_rgb8, out.p, n, hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }

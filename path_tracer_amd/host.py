@@ -17,7 +17,7 @@ _fp = C.POINTER(C.c_float)
 
 HOST_SIGNATURES = {
     "pth_last_error": (C.c_char_p, []),
-    "pth_generate_scene": (C.c_int, [C.c_int, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_int,
+    "pth_generate_scene": (C.c_int, [C.c_int, C.c_uint, C.c_uint, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                      _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp]),
     "pth_camera_setup": (None, [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
     "pth_read_settings": (C.c_int, [C.c_char_p, _dp]),
@@ -60,13 +60,14 @@ def _p(a, t=_dp):
     return a.ctypes.data_as(t)
 
 
-def generate_scene(count=250, seed_a=1, seed_b=2, half_extent=10.0, diffuse_below=0.6, metal_below=0.9):
-    """Path Tracer.cpp:182-260: five fixed + up to `count` random spheres, in list order."""
+def generate_scene(count=250, seed_a=1, seed_b=2, half_extent=10.0, diffuse_below=0.6, metal_below=0.9, use_grid=True):
+    """Path Tracer.cpp:182-260: five fixed + up to `count` random spheres, in list order. use_grid: the overlap
+    test goes through a uniform grid instead of the reference's scan of every object (same scene, bit for bit)."""
     lib = load_host_library()
     cap = count + 5
     f = {k: np.zeros(cap) for k in SCENE_KEYS}
     kind = np.zeros(cap, dtype=np.int32)
-    n = lib.pth_generate_scene(count, seed_a, seed_b, half_extent, diffuse_below, metal_below, cap,
+    n = lib.pth_generate_scene(count, seed_a, seed_b, half_extent, diffuse_below, metal_below, 1 if use_grid else 0, cap,
                                _p(f["cx"]), _p(f["cy"]), _p(f["cz"]), _p(f["r"]), _p(kind, _ip),
                                _p(f["ar"]), _p(f["ag"]), _p(f["ab"]), _p(f["fuzz"]), _p(f["ior"]))
     out = {k: v[:n].copy() for k, v in f.items()}

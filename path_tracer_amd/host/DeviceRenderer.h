@@ -61,6 +61,19 @@ public:
         check(pt_ray_count(m_handle, &m_rays), "pt_ray_count");
         return out;
     }
+    // Gamma, clamp and quantise on the device (writeColour, Path Tracer.cpp:62-74): r g b bytes, top row first.
+    std::vector<unsigned char> quantised(int samplesPerPixel) {
+        std::vector<unsigned char> out(std::size_t(m_width) * m_height * 3);
+        check(pt_quantise_rgb8(m_handle, m_width, m_height, samplesPerPixel, nullptr, out.data()), "pt_quantise_rgb8");
+        check(pt_ray_count(m_handle, &m_rays), "pt_ray_count");
+        return out;
+    }
+    // Resume a frame from saved sums (the float buffer read with pixels() / pt_read_accum).
+    void resume(int width, int height, const std::vector<float>& sums) {
+        if (sums.size() != std::size_t(width) * height * 3) throw DeviceError("resume: buffer size does not match the image");
+        check(pt_write_accum(m_handle, width, height, sums.data()), "pt_write_accum");
+        m_width = width; m_height = height;
+    }
     std::uint64_t raysTraced() const { return m_rays; }
 
     // Milliseconds the sample-loop kernel ran for, summed over the renders since the last call.

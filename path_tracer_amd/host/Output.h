@@ -29,5 +29,17 @@ inline void writeImage(std::ostream& out, const std::vector<PhysicsVector<3>>& p
     for (const auto& p : pixels) writeColour(out, p, samplesPerPixel);
 }
 
+// The same picture from bytes already quantised on the device (pt_quantise_rgb8): ASCII P3, byte for
+// byte what writeImage produces, or binary P6 (three bytes per pixel instead of up to twelve characters).
+inline void writeImageP3(std::ostream& out, const std::vector<unsigned char>& rgb8, int width, int height) {
+    out << "P3\n" << width << ' ' << height << "\n255\n";
+    for (std::size_t i = 0; i + 2 < rgb8.size(); i += 3)
+        out << int(rgb8[i]) << ' ' << int(rgb8[i + 1]) << ' ' << int(rgb8[i + 2]) << '\n';
+}
+inline void writeImageP6(std::ostream& out, const std::vector<unsigned char>& rgb8, int width, int height) {
+    out << "P6\n" << width << ' ' << height << "\n255\n";
+    out.write(reinterpret_cast<const char*>(rgb8.data()), std::streamsize(rgb8.size()));
+}
+
 }   // namespace dp
 #endif

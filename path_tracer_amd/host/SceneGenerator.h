@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <memory>
 #include <random>
+#include <vector>
 
 #include "Dielectric.h"
 #include "HittableList.h"
@@ -26,6 +27,38 @@ struct SceneOptions {
     double halfExtent = 10.0;         // Path Tracer.cpp:218
     double diffuseBelow = 0.6;        // Path Tracer.cpp:242
     double metalBelow = 0.9;          // Path Tracer.cpp:247
+    bool useGrid = true;              // overlap test through a uniform grid: same decisions, same scene
+};
+
+// Uniform grid over the placement square for the overlap test of Path Tracer.cpp:220-226. The
+// reference scans every object placed so far (O(n) per attempt, O(n^2) per scene); whether a
+// candidate clips ANY object does not depend on the scan order, so asking only the cells a clipping
+// sphere could lie in gives the same accept / reject decisions, consumes the same random numbers
+// and yields the same scene bit for bit. Random spheres have r < 0.4, so two of them can only clip
+// when their centres are within 0.8 in x and z: one ring of 0.8-wide cells. The five fixed spheres
+// (radius 1 and 1000) are always tested directly.
+class PlacementGrid {
+    static constexpr double kCell = 0.8;
+    double m_lo;
+    int m_n;
+    std::vector<std::vector<std::size_t>> m_cells;   // indices into the world list
+    int cellOf(double v) const {
+        int c = static_cast<int>((v - m_lo) / kCell);
+        return c < 0 ? 0 : (c >= m_n ? m_n - 1 : c);
+    }
+
+public:
+    explicit PlacementGrid(double halfExtent) : m_lo(-halfExtent), m_n(static_cast<int>(2 * halfExtent / kCell) + 1), m_cells(std::size_t(m_n) * m_n) {}
+    void insert(const PhysicsVector<3>& c, std::size_t index) { m_cells[std::size_t(cellOf(c.z())) * m_n + cellOf(c.x())].push_back(index); }
+    template <class F>
+    bool anyNear(const PhysicsVector<3>& c, F&& clips) const {
+        const int cx = cellOf(c.x()), cz = cellOf(c.z());
+        for (int z = (cz > 0 ? cz - 1 : 0); z <= (cz + 1 < m_n ? cz + 1 : m_n - 1); ++z)
+            for (int x = (cx > 0 ? cx - 1 : 0); x <= (cx + 1 < m_n ? cx + 1 : m_n - 1); ++x)
+                for (std::size_t idx : m_cells[std::size_t(z) * m_n + x])
+                    if (clips(idx)) return true;
+        return false;
+    }
 };
 
 using colour = PhysicsVector<3>;
@@ -50,6 +83,11 @@ inline int addRandomSpheres(HittableList& world, const SceneOptions& opt) {
     std::mt19937 engineA{opt.seedA}, engineB{opt.seedB};
     auto between = [&engineA](double lo, double hi) { return std::uniform_real_distribution<double>{lo, hi}(engineA); };
     int placed = 0;
+    const std::size_t fixedCount = world.length();      // objects already there are tested one by one
+    PlacementGrid grid(opt.halfExtent);
+    auto clips = [&world](const point3D& center, double radius, std::size_t k) {
+        return (center - world[k].getCenter()).length() < radius + world[k].minDistanceApart();   // Path Tracer.cpp:222
+    };
     for (int i = 0; i < opt.numberOfSpheres; ++i) {
         const double selector = between(0, 1);
         const double radius = between(0.1, 0.4);
@@ -61,9 +99,12 @@ inline int addRandomSpheres(HittableList& world, const SceneOptions& opt) {
             const double z = between(-opt.halfExtent, opt.halfExtent);
             center = point3D{x, radius, z};
             fits = true;
-            for (std::size_t k = 0; k < world.length(); ++k) {
-                if ((center - world[k].getCenter()).length() < radius + world[k].minDistanceApart()) { fits = false; break; }
+            const std::size_t scanUpTo = opt.useGrid ? fixedCount : world.length();
+            for (std::size_t k = 0; k < scanUpTo; ++k) {
+                if (clips(center, radius, k)) { fits = false; break; }
             }
+            if (fits && opt.useGrid)
+                fits = !grid.anyNear(center, [&](std::size_t k) { return clips(center, radius, k); });
             if (fits) break;
         }
         if (!fits) break;             // no room left: the whole generation ends (Path Tracer.cpp:236)
@@ -77,6 +118,7 @@ inline int addRandomSpheres(HittableList& world, const SceneOptions& opt) {
         } else {
             material = std::make_shared<Dielectric>(1.5);
         }
+        grid.insert(center, world.length());
         world.add(std::make_shared<Sphere>(center, radius, material));
         ++placed;
     }

@@ -34,6 +34,7 @@ struct Settings {
     std::uint64_t renderSeed = 42;
     double sceneHalfExtent = 10.0;
     int numberOfGPUs = 1;
+    bool binaryOutput = false;        // outputFormat = P6 (the reference writes ASCII P3)
 
     int imageHeight() const { return static_cast<int>(imageWidth / imageAspectRatio); }   // Path Tracer.cpp:176
 };
@@ -60,6 +61,7 @@ inline Settings readSettings(ConfigReader& config, std::ostream* log = nullptr) 
         if (config.contains("renderSeed")) s.renderSeed = std::uint64_t(config.readValue("renderSeed", 42L));
         if (config.contains("sceneHalfExtent")) s.sceneHalfExtent = config.readValue("sceneHalfExtent", s.sceneHalfExtent);
         if (config.contains("numberOfGPUs")) s.numberOfGPUs = config.readValue("numberOfGPUs", s.numberOfGPUs);
+        if (config.contains("outputFormat")) s.binaryOutput = config.readValue("outputFormat") == "P6";
         config.clear();
         if (log) *log << "All values read from file correctly.\n";
     } catch (ConfigReader::ConfigException& except) {

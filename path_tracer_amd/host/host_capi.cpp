@@ -44,13 +44,13 @@ const char* pth_last_error() { return g_err.c_str(); }
 
 // Five fixed + up to `count` random spheres, flattened in list order. Returns the sphere count.
 int pth_generate_scene(int count, unsigned seedA, unsigned seedB, double half_extent, double diffuse_below,
-                       double metal_below, int cap, double* cx, double* cy, double* cz, double* r, int* kind, double* ar,
+                       double metal_below, int use_grid, int cap, double* cx, double* cy, double* cz, double* r, int* kind, double* ar,
                        double* ag, double* ab, double* fuzz, double* ior) {
     HittableList world;
     dp::addFixedSpheres(world);
     dp::SceneOptions opt;
     opt.numberOfSpheres = count; opt.seedA = seedA; opt.seedB = seedB; opt.halfExtent = half_extent;
-    opt.diffuseBelow = diffuse_below; opt.metalBelow = metal_below;
+    opt.diffuseBelow = diffuse_below; opt.metalBelow = metal_below; opt.useGrid = use_grid != 0;
     dp::addRandomSpheres(world, opt);
     return flatten_out(world, cap, cx, cy, cz, r, kind, ar, ag, ab, fuzz, ior);
 }

@@ -50,16 +50,17 @@ int main(int argc, char** argv) {
             for (auto& d : devs) hs.push_back(d->handle());
             if (pt_reduce(hs.data(), gpus, 0) != 0) throw dp::DeviceError(std::string("pt_reduce: ") + pt_last_error(hs[0]));
         }
-        const std::vector<dp::PhysicsVector<3>> pixels = devs[0]->pixels();
+        const std::vector<unsigned char> bytes = devs[0]->quantised(s.raysPerPixel);   // output stage on the device
         const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::uint64_t rays = 0;
-        for (auto& d : devs) { (void)d->pixels(); rays += d->raysTraced(); }
+        for (auto& d : devs) { (void)d->quantised(s.raysPerPixel); rays += d->raysTraced(); }
         const double samples = double(width) * height * s.raysPerPixel;
         std::cout << "Rendered " << width << "x" << height << " at " << s.raysPerPixel << " spp on " << gpus << " GPU(s) in " << seconds
                   << " s: " << samples / seconds / 1e6 << " Msamples/s, " << double(rays) / seconds / 1e9 << " Grays/s\n";
 
         std::ofstream out(outPath, std::ios::out | std::ios::binary);
-        dp::writeImage(out, pixels, width, height, s.raysPerPixel);
+        if (s.binaryOutput) dp::writeImageP6(out, bytes, width, height);
+        else dp::writeImageP3(out, bytes, width, height);                               // byte for byte the reference's file
     } catch (const std::exception& e) {
         std::cerr << "pathtracer: " << e.what() << '\n';
         return 1;

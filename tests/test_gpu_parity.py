@@ -402,3 +402,48 @@ def test_large_scene_10k_spheres(dev, orc):
     orc.scene_free(hs)
     diff = np.abs(img - ref).max(axis=2) / 2
     assert (diff > 2e-3).mean() < 0.03 and abs(rays - ref_rays) < 0.01 * ref_rays
+
+
+def test_output_stage_on_device_is_byte_exact(dev, scene250):
+    """gamma + clamp + quantise on the device give the bytes the reference's writeColour
+    prints (Path Tracer.cpp:62-74), checked against the host-side writer on the same sums."""
+    from path_tracer_amd import host
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    W, H, spp = 200, 113, 6
+    img, _ = dev.render_image(W, H, spp, 50, seed=3)
+    q = dev.quantise_rgb8(W, H, spp)
+    lines = host.format_ppm(img, spp).decode().split("\n")
+    ref = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + W * H]], dtype=np.uint8).reshape(H, W, 3)
+    assert np.array_equal(q, ref)
+    # extremes: zero, exactly one per sample, far above one
+    sums = np.zeros((4, 8, 3), dtype=np.float32)
+    sums[0, 1] = spp
+    sums[0, 2] = 100 * spp
+    sums[0, 3] = 0.25 * spp
+    dev.write_accum(sums)
+    q = dev.quantise_rgb8(8, 4, spp)
+    assert list(q[0, :4, 0]) == [0, 255, 255, 128]
+
+
+def test_resume_from_saved_sums(dev, scene250):
+    """a frame continued from a saved buffer equals the frame rendered in one go."""
+    from path_tracer_amd import Device
+    sc, cam, hs = scene250
+    use(dev, sc, cam)
+    W, H = 96, 54
+    dev.clear_accum(W, H)
+    dev.render(W, H, 0, 5, 50, 11)
+    dev.render(W, H, 5, 9, 50, 11)
+    whole = dev.read_accum(W, H)
+    dev.clear_accum(W, H)
+    dev.render(W, H, 0, 5, 50, 11)
+    saved = dev.read_accum(W, H)
+    other = Device(0)
+    other.set_scene(sc)
+    other.set_camera(cam)
+    other.write_accum(saved)
+    other.render(W, H, 5, 9, 50, 11)
+    resumed = other.read_accum(W, H)
+    other.close()
+    assert np.array_equal(resumed, whole)

@@ -161,3 +161,14 @@ def test_ppm_is_byte_exact(orc, kat):
     lines = host.format_ppm(s, 4).decode().split("\n")
     assert lines[:3] == ["P3", "%d 1" % len(vals), "255"]
     assert lines[3:3 + len(vals)] == [" ".join([str(v["value"])] * 3) for v in vals]
+
+
+def test_grid_generator_is_bit_identical_to_the_full_scan():
+    """the uniform-grid overlap test takes the same accept/reject decisions as the
+    reference's scan of every object (Path Tracer.cpp:220-226), so the scene does not change."""
+    for count, a, b, ext in [(250, 1, 2, 10.0), (500, 9, 4, 10.0), (3000, 5, 6, 12.0), (2000, 1, 2, 2.0), (4000, 2, 3, 45.0)]:
+        g = host.generate_scene(count, a, b, half_extent=ext, use_grid=True)
+        r = host.generate_scene(count, a, b, half_extent=ext, use_grid=False)
+        assert len(g["kind"]) == len(r["kind"])
+        for k in g:
+            assert np.array_equal(g[k], r[k]), (count, a, b, ext, k)
