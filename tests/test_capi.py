@@ -82,3 +82,20 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_hand_written_scalar_loads_are_not_touched_in_flight(tmp_path):
+    """pt_device.h issues s_load_dwordx16 from inline asm and waits for it in a separate statement. Compile to
+    assembly and check that nothing between a load and its wait reads or writes the registers being loaded."""
+    import shutil
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    out = str(tmp_path / "pt_hip.s")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out,
+                           os.path.join(ROOT, "path_tracer_amd", "csrc", "pt_hip.hip")], stderr=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_sload
+    n, problems = check_sload.check(out)
+    assert n >= 4 and not problems, problems
