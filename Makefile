@@ -6,7 +6,7 @@ HIPFLAGS ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functi
 
 all: $(LIBDIR)/libpt_hip.so host oracle
 
-$(LIBDIR)/libpt_hip.so: path_tracer_amd/csrc/pt_hip.hip path_tracer_amd/csrc/pt_device.h include/pt_hip.h
+$(LIBDIR)/libpt_hip.so: path_tracer_amd/csrc/pt_hip.hip path_tracer_amd/csrc/pt_device.h path_tracer_amd/csrc/pt_grid.h include/pt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $< -ldl
 
@@ -16,7 +16,7 @@ host:
 oracle:
 	$(MAKE) -C oracle
 
-asm: path_tracer_amd/csrc/pt_hip.hip path_tracer_amd/csrc/pt_device.h
+asm: path_tracer_amd/csrc/pt_hip.hip path_tracer_amd/csrc/pt_device.h path_tracer_amd/csrc/pt_grid.h
 	@mkdir -p tools/build
 	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage -o tools/build/pt_hip.s $< 2> tools/build/pt_hip.resources.txt
 

@@ -61,6 +61,18 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
                  const int* kind, const double* albedo_r, const double* albedo_g, const double* albedo_b,
                  const double* fuzz, const double* ior);
 
+/* Optional: how pt_render and pt_scan look for the closest hit. PT_ACCEL_NONE (the default) tests every
+ * sphere for every ray, as HittableList::isHit does (HittableList.cpp:27). PT_ACCEL_GRID walks a uniform
+ * grid built from the scene and tests only the spheres entered in the cells the ray crosses; the hit
+ * returned obeys the same rule (closest t in range, ties to the later list index). Meant for scenes of
+ * thousands of spheres; its throughput is not counted in the FP32 roofline figure, whose unit is one
+ * ray-sphere test of the full scan. May be called before or after pt_set_scene. */
+enum { PT_ACCEL_NONE = 0, PT_ACCEL_GRID = 1 };
+int pt_set_accel(pt_handle h, int mode);
+/* Shape of the grid in use: info = nx, ny, nz, spheres kept in the linearly scanned "big" list, entries
+ * in all cells, entries in the fullest cell; *cell_edge (may be NULL) the cell size. */
+int pt_accel_info(pt_handle h, int info[6], double* cell_edge);
+
 /* The seven values Camera::setupCamera derives (Camera.cpp:27-31) and Camera::getCurrentRay reads
  * (Camera.cpp:38-46): position, lower-left corner, horizontal, vertical, unit u, unit v, lens radius. */
 int pt_set_camera(pt_handle h, const double position[3], const double lower_left[3], const double horizontal[3],

@@ -24,6 +24,8 @@ SIGNATURES = {
     "pt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pt_synchronize": (C.c_int, [C.c_void_p]),
     "pt_set_scene": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp]),
+    "pt_set_accel": (C.c_int, [C.c_void_p, C.c_int]),
+    "pt_accel_info": (C.c_int, [C.c_void_p, _ip, _dp]),
     "pt_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double]),
     "pt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, _u64p]),
     "pt_clear_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -120,6 +122,17 @@ class Device:
                                        _p(kind, _ip), _p(a["ar"], _dp), _p(a["ag"], _dp), _p(a["ab"], _dp),
                                        _p(a["fuzz"], _dp), _p(a["ior"], _dp)), "pt_set_scene")
         self.n_spheres = n
+
+    def set_accel(self, mode):
+        """0: test every sphere (default); 1: uniform grid (include/pt_hip.h, PT_ACCEL_GRID)."""
+        self._ck(self.lib.pt_set_accel(self.h, int(mode)), "pt_set_accel")
+
+    def accel_info(self):
+        info = np.zeros(6, dtype=np.int32)
+        cell = C.c_double(0)
+        self._ck(self.lib.pt_accel_info(self.h, _p(info, _ip), C.byref(cell)), "pt_accel_info")
+        return dict(dims=tuple(int(v) for v in info[:3]), big=int(info[3]), entries=int(info[4]), fullest=int(info[5]),
+                    cell=cell.value)
 
     def set_camera(self, cam19):
         """cam19: position, lower_left, horizontal, vertical, u, v (3 each), lens radius."""

@@ -1,0 +1,111 @@
+// pt_grid.h — optional closest-hit search through a uniform grid, for scenes
+// where the linear scan of HittableList.cpp:27 over every sphere dominates (10k spheres and more).
+//
+// The answer is the one HittableList::isHit gives (closest t in range, ties to the later list index,
+// HittableList.cpp:28-31 with Sphere.cpp:18); only the set of spheres looked at shrinks:
+//   big list   spheres that would cover many cells (the ground sphere of Path Tracer.cpp:183) stay in a
+//              short list scanned with the scalar-register scan of pt_device.h;
+//   grid       every other sphere is entered in each cell its box touches. A lane walks the cells its
+//              ray crosses (3-D DDA) and tests the spheres entered there, relative to the ray origin:
+//              oc = c - o, b = oc.dh, T = r^2 - |oc - b dh|^2, roots b -+ sqrt(T) (Sphere.cpp:6-19 in
+//              unit-direction form, the discriminant written so that it keeps its digits at any
+//              distance). The walk ends when the closest hit so far lies before the exit of the current
+//              cell, or the ray leaves the grid.
+// Lanes diverge here by design (one path per lane, one cell list per lane): loads are per-lane vector
+// loads that hit in L2 (the whole structure is a few hundred KB), not scalar broadcasts.
+#pragma once
+
+#include "pt_device.h"
+
+namespace ptd {
+
+struct GridDev {
+    const uint32_t* cell_start;   // nx*ny*nz + 1 offsets into items / ids
+    const float4* items;          // per entry: cx, cy, cz, r^2 of the sphere (floats of the double scene)
+    const int* ids;               // per entry: list index of the sphere
+    const int* big_ids;           // list index of each sphere of the big list
+    const int* big_local;         // per list index: position in the big list, or -1
+    SceneDev big;                 // scan records of the big list (geom / mat unused)
+    f3 gmin, gmax;                // box the cells tile
+    float cell, inv_cell;         // cell edge
+    int nx, ny, nz;
+};
+
+PT_DEV float nonzero(float d) { return __builtin_fabsf(d) < 1e-12f ? __builtin_copysignf(1e-12f, d) : d; }
+
+// Same contract as scan_spheres (pt_device.h): best_i is a LIST index.
+PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+    // ---- the big list, through the scalar-register scan; its indices are positions in that list ----
+    int prev_local = -1;
+    if (prev >= 0) prev_local = G.big_local[prev];
+    scan_spheres(G.big, o, dh, tmin, prev_local, self_t, best_t, best_i);
+    if (best_i >= 0) best_i = G.big_ids[best_i];
+
+    // ---- clip the ray to the box of the grid ----
+    const f3 dn = mk3(nonzero(dh.x), nonzero(dh.y), nonzero(dh.z));   // the walk only: a zero component would make 0 * inf
+    const f3 inv = mk3(fast_rcp(dn.x), fast_rcp(dn.y), fast_rcp(dn.z));
+    const f3 ta = (G.gmin - o) * inv, tb = (G.gmax - o) * inv;
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ta.x, tb.x), __builtin_fminf(ta.y, tb.y)),
+                                       __builtin_fmaxf(__builtin_fminf(ta.z, tb.z), 0.0f));
+    const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ta.x, tb.x), __builtin_fmaxf(ta.y, tb.y)),
+                                        __builtin_fminf(__builtin_fmaxf(ta.z, tb.z), best_t));
+    bool live = t_in <= t_out;
+
+    // ---- the cell the ray enters at, the distance to the next cell wall on each axis ----
+    const f3 q = (fma3(dh, t_in, o) - G.gmin) * G.inv_cell;
+    const int ix = min(max(int(__builtin_floorf(q.x)), 0), G.nx - 1);
+    const int iy = min(max(int(__builtin_floorf(q.y)), 0), G.ny - 1);
+    const int iz = min(max(int(__builtin_floorf(q.z)), 0), G.nz - 1);
+    const bool fx = dn.x > 0.0f, fy = dn.y > 0.0f, fz = dn.z > 0.0f;
+    float tmx = (__builtin_fmaf(float(ix + (fx ? 1 : 0)), G.cell, G.gmin.x) - o.x) * inv.x;
+    float tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), G.cell, G.gmin.y) - o.y) * inv.y;
+    float tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), G.cell, G.gmin.z) - o.z) * inv.z;
+    const float tdx = G.cell * __builtin_fabsf(inv.x), tdy = G.cell * __builtin_fabsf(inv.y), tdz = G.cell * __builtin_fabsf(inv.z);
+    int rx = fx ? G.nx - 1 - ix : ix, ry = fy ? G.ny - 1 - iy : iy, rz = fz ? G.nz - 1 - iz : iz;   // cells left on each axis
+    const int sx = fx ? 1 : -1, sy = fy ? G.nx : -G.nx, sz = fz ? G.nx * G.ny : -(G.nx * G.ny);
+    int ci = (iz * G.ny + iy) * G.nx + ix;
+
+    uint32_t k = 0, kend = 0;
+    if (live) { k = G.cell_start[ci]; kend = G.cell_start[ci + 1]; }
+    // Every pass of this loop either consumes one entry of the current cell or moves one cell along one
+    // axis, and a lane leaves when an axis runs out of cells: at most nx + ny + nz + entries passes.
+    while (live) {
+        if (k < kend) {
+            const float4 s = G.items[k];
+            const int id = G.ids[k];
+            ++k;
+            const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);                  // Sphere.cpp:6 (sign folded into b)
+            const float b = dot(oc, dh);                                          // :8
+            // disc = r^2 - (distance from the centre to the ray's line)^2, from the perpendicular part of oc:
+            // b*b - |oc|^2 cancels badly once the sphere is far away compared with its radius
+            const f3 perp = fma3(dh, -b, oc);
+            const float T = __builtin_fmaf(-perp.z, perp.z, __builtin_fmaf(-perp.y, perp.y, __builtin_fmaf(-perp.x, perp.x, s.w)));   // :9-10
+            const float sq = fast_sqrt(T);                                        // NaN for T < 0: compares below are false
+            const float t1 = b - sq, t2 = b + sq;
+            const float t = (t1 >= tmin) ? t1 : t2;                               // :17-19
+            const bool closer = (t < best_t) | ((t == best_t) & (id > best_i));   // HittableList.cpp:28-31: later index wins ties
+            const bool ok = (T >= 0.0f) & (id != prev) & (t >= tmin) & closer;
+            best_t = ok ? t : best_t;
+            best_i = ok ? id : best_i;
+        } else {
+            const float t_exit = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
+            if (best_t < t_exit) break;                   // the closest hit lies inside the cells already walked
+            int left;
+            if (tmx <= tmy && tmx <= tmz) { tmx += tdx; ci += sx; left = --rx; }
+            else if (tmy <= tmz)          { tmy += tdy; ci += sy; left = --ry; }
+            else                          { tmz += tdz; ci += sz; left = --rz; }
+            if (left < 0 || t_exit > t_out) break;        // out of the grid
+            k = G.cell_start[ci];
+            kend = G.cell_start[ci + 1];
+        }
+    }
+
+    // ---- the sphere the ray starts on, when it lives in the grid (the big list handled its own) ----
+    {
+        const bool ok = (prev >= 0) & (prev_local < 0) & (self_t >= tmin) & (self_t <= best_t);
+        best_t = ok ? self_t : best_t;
+        best_i = ok ? prev : best_i;
+    }
+}
+
+}   // namespace ptd

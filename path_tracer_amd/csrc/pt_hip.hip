@@ -1,7 +1,8 @@
 // pt_hip.hip — kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h).
 //
 // Kernels
-//   k_render   the sample loop: per-lane iterative bounce loop with path regeneration, persistent
+//   k_render<MODE>  the sample loop (MODE 0: linear scan of every sphere, the default; MODE 1: the same
+//              loop with the closest-hit search through the uniform grid of pt_grid.h): per-lane iterative bounce loop with path regeneration, persistent
 //              waves. A wave (one 64-thread workgroup) pulls jobs = an 8x8 pixel tile x a chunk of
 //              samples from a global counter and hands (pixel, sample) items to its lanes as their
 //              paths end, so every lane stays inside the sphere scan. Replaces process_row /
@@ -25,6 +26,7 @@
 
 #include "../../include/pt_hip.h"
 #include "pt_device.h"
+#include "pt_grid.h"
 
 using namespace ptd;
 
@@ -41,6 +43,7 @@ struct RenderParams {
     float inv_w1, inv_h1;
     CameraDev cam;
     SceneDev scene;
+    GridDev grid;                    // read by k_render<1> only
     unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
     unsigned long long* ray_count;   // rays of this call
     unsigned int* job_counter;       // next job to hand out, zero at launch
@@ -85,7 +88,11 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 6
 #endif
-__global__ void __launch_bounds__(64, PT_WAVES_PER_EU) k_render(const RenderParams P) {
+#ifndef PT_GRID_WAVES_PER_EU
+#define PT_GRID_WAVES_PER_EU 8      // the grid walk waits on memory: more waves to switch between
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER_EU) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[2 * 192];
     const int lane = threadIdx.x;
 #pragma unroll
@@ -117,7 +124,8 @@ __global__ void __launch_bounds__(64, PT_WAVES_PER_EU) k_render(const RenderPara
         if (active) {
             ++rays;
             float bt; int bi;
-            scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if constexpr (MODE == 0) scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            else scan_grid(P.grid, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 unsigned long long* a = acc + 192 * lbank + slot * 3;
@@ -246,7 +254,8 @@ __global__ void k_quantise(const float* sum, size_t n, double scale, unsigned ch
     }
 }
 
-__global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, double t_min, double* t, int* idx,
+template <int MODE>
+__global__ void k_scan(SceneDev sc, GridDev grid, int n, const double* o, const double* d, double t_min, double* t, int* idx,
                        double* p, double* nrm, int* front) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -255,7 +264,8 @@ __global__ void k_scan(SceneDev sc, int n, const double* o, const double* d, dou
     float len;
     const f3 dh = normalise(rd, len);
     float bt; int bi;
-    scan_spheres(sc, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
+    if constexpr (MODE == 0) scan_spheres(sc, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
+    else scan_grid(grid, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
     idx[k] = bi;
     if (bi < 0) {
         t[k] = 0; front[k] = 0;
@@ -334,6 +344,20 @@ struct pt_context {
     MatRec* d_mat = nullptr;
     int n = 0, n_pad = 0;
     bool have_scene = false, have_camera = false;
+    // optional grid search (pt_set_accel): built from the host copy of the geometry on first use
+    int accel = PT_ACCEL_NONE;
+    bool grid_ready = false;
+    std::vector<double> h_cx, h_cy, h_cz, h_r;
+    uint32_t* d_cell_start = nullptr;
+    float4* d_items = nullptr;
+    int* d_item_ids = nullptr;
+    int* d_big_ids = nullptr;
+    int* d_big_local = nullptr;
+    float* d_big_scan = nullptr;
+    GridDev grid;
+    int grid_info[6] = {0, 0, 0, 0, 0, 0};     // nx, ny, nz, spheres in the big list, entries, fullest cell
+    double grid_cell_scale = 4.0;              // cell edge = scale x median radius (PT_GRID_CELL_SCALE)
+    int resident_waves_grid = 0;
     CameraDev cam;
     // frame
     unsigned long long* d_fx = nullptr;
@@ -385,6 +409,135 @@ static SceneDev scene_dev(pt_handle h) {
     return s;
 }
 
+// Scan records (see SceneDev) of the spheres `which` lists, padded to a multiple of four plus the two
+// never-hit quads the pipelined loads may touch.
+static std::vector<float> scan_records(const std::vector<int>& which, const double* cx, const double* cy, const double* cz,
+                                       const double* r, int* n_pad_out) {
+    const int n = int(which.size());
+    const int n_pad = (n + 3) & ~3;
+    std::vector<float> scan(size_t(n_pad + 8) * 4);
+    for (int i = 0; i < n_pad + 8; ++i) {
+        float* rec = scan.data() + 8 * (i >> 1) + (i & 1);
+        if (i < n) {
+            const int s = which[i];
+            rec[0] = float(cx[s]); rec[2] = float(cy[s]); rec[4] = float(cz[s]);
+            // -K from the float centre the scan multiplies with, so that b*b + 2 o.c - |o|^2 - K is
+            // the discriminant of the sphere tier 1 actually sees; r^2 in double.
+            const double fx = rec[0], fy = rec[2], fz = rec[4];
+            rec[6] = float(r[s] * r[s] - (fx * fx + fy * fy + fz * fz));   // -K
+        } else {
+            rec[0] = rec[2] = rec[4] = 0.0f;
+            rec[6] = -1e30f;                     // -K: never flagged
+        }
+    }
+    *n_pad_out = n_pad;
+    return scan;
+}
+
+// The uniform grid of pt_grid.h from the host copy of the geometry. Cell edge = grid_cell_scale x the
+// median radius; a sphere whose box would span more than four cells on an axis goes to the big list.
+static int build_grid(pt_handle h) {
+    const int n = h->n;
+    const double *cx = h->h_cx.data(), *cy = h->h_cy.data(), *cz = h->h_cz.data(), *r = h->h_r.data();
+    std::vector<double> rs(h->h_r);
+    std::nth_element(rs.begin(), rs.begin() + n / 2, rs.end());
+    double cell = h->grid_cell_scale * rs[n / 2];
+    std::vector<int> big, small;
+    double lo[3], hi[3];
+    int dims[3];
+    for (int attempt = 0;; ++attempt) {
+        big.clear(); small.clear();
+        for (int i = 0; i < n; ++i) (2.0 * r[i] > 3.0 * cell ? big : small).push_back(i);
+        for (int a = 0; a < 3; ++a) { lo[a] = 0; hi[a] = 0; }
+        bool first = true;
+        for (int i : small) {
+            const double c[3] = {cx[i], cy[i], cz[i]};
+            for (int a = 0; a < 3; ++a) {
+                if (first || c[a] - r[i] < lo[a]) lo[a] = c[a] - r[i];
+                if (first || c[a] + r[i] > hi[a]) hi[a] = c[a] + r[i];
+            }
+            first = false;
+        }
+        double cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            dims[a] = std::max(1, int(std::ceil((hi[a] - lo[a]) / cell + 1e-6)));
+            cells *= dims[a];
+        }
+        if ((dims[0] <= 1024 && dims[1] <= 1024 && dims[2] <= 1024 && cells <= double(1 << 23)) || attempt >= 40) break;
+        cell *= 1.5;      // a few far-flung small spheres: coarser cells rather than an enormous table
+    }
+    // pad: the walk is fp32 (entry point, wall distances); boxes grow by far more than its rounding
+    double maxabs = 1.0;
+    for (int a = 0; a < 3; ++a) maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    const double pad = 1e-3 * cell + 1e-5 * maxabs;
+    const float gmin[3] = {float(lo[0] - pad), float(lo[1] - pad), float(lo[2] - pad)};
+    const float fcell = float(cell);
+    for (int a = 0; a < 3; ++a) dims[a] = std::max(1, int(std::ceil((hi[a] + pad - double(gmin[a])) / double(fcell))));
+    const size_t n_cells = size_t(dims[0]) * dims[1] * dims[2];
+    auto cell_range = [&](int i, int a, int& c0, int& c1) {
+        const double c[3] = {cx[i], cy[i], cz[i]};
+        c0 = int(std::floor((c[a] - r[i] - pad - double(gmin[a])) / double(fcell)));
+        c1 = int(std::floor((c[a] + r[i] + pad - double(gmin[a])) / double(fcell)));
+        c0 = std::min(std::max(c0, 0), dims[a] - 1);
+        c1 = std::min(std::max(c1, 0), dims[a] - 1);
+    };
+    std::vector<uint32_t> start(n_cells + 1, 0u), fill;
+    std::vector<float4> items;
+    std::vector<int> ids;
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0 counts the entries of each cell, pass 1 fills them (list order within a cell)
+        if (pass == 1) {
+            uint32_t run = 0;
+            for (size_t c = 0; c <= n_cells; ++c) { const uint32_t v = start[c]; start[c] = run; run += v; }
+            fill.assign(start.begin(), start.end() - 1);
+            items.assign(start[n_cells], float4{0, 0, 0, 0});
+            ids.assign(start[n_cells], 0);
+        }
+        for (int i : small) {
+            int x0, x1, y0, y1, z0, z1;
+            cell_range(i, 0, x0, x1); cell_range(i, 1, y0, y1); cell_range(i, 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) {
+                        const size_t c = (size_t(z) * dims[1] + y) * dims[0] + x;
+                        if (pass == 0) { ++start[c]; continue; }
+                        const uint32_t at = fill[c]++;
+                        items[at] = float4{float(cx[i]), float(cy[i]), float(cz[i]), float(r[i] * r[i])};
+                        ids[at] = i;
+                    }
+        }
+    }
+    int fullest = 0;
+    for (size_t c = 0; c < n_cells; ++c) fullest = std::max(fullest, int(start[c + 1] - start[c]));
+    const int n_entries = int(start[n_cells]);
+    std::vector<int> big_local(n, -1);
+    for (size_t b = 0; b < big.size(); ++b) big_local[big[b]] = int(b);
+    int big_pad = 0;
+    std::vector<float> big_scan = scan_records(big, cx, cy, cz, r, &big_pad);
+    if (items.empty()) { items.push_back(float4{0, 0, 0, 0}); ids.push_back(0); }   // never read: no cell points at it
+    std::vector<int> big_ids(big);
+    if (big_ids.empty()) big_ids.push_back(0);
+    int rc;
+    if ((rc = upload(h, &h->d_cell_start, start))) return rc;
+    if ((rc = upload(h, &h->d_items, items))) return rc;
+    if ((rc = upload(h, &h->d_item_ids, ids))) return rc;
+    if ((rc = upload(h, &h->d_big_ids, big_ids))) return rc;
+    if ((rc = upload(h, &h->d_big_local, big_local))) return rc;
+    if ((rc = upload(h, &h->d_big_scan, big_scan))) return rc;
+    GridDev& g = h->grid;
+    g.cell_start = h->d_cell_start; g.items = h->d_items; g.ids = h->d_item_ids;
+    g.big_ids = h->d_big_ids; g.big_local = h->d_big_local;
+    g.big.scan = h->d_big_scan; g.big.geom = nullptr; g.big.mat = nullptr; g.big.n = int(big.size()); g.big.n_pad = big_pad;
+    g.gmin = f3{gmin[0], gmin[1], gmin[2]};
+    g.gmax = f3{gmin[0] + fcell * float(dims[0]), gmin[1] + fcell * float(dims[1]), gmin[2] + fcell * float(dims[2])};
+    g.cell = fcell; g.inv_cell = 1.0f / fcell;
+    g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2];
+    h->grid_info[0] = dims[0]; h->grid_info[1] = dims[1]; h->grid_info[2] = dims[2];
+    h->grid_info[3] = int(big.size()); h->grid_info[4] = n_entries; h->grid_info[5] = fullest;
+    h->grid_ready = true;
+    return 0;
+}
+
 extern "C" {
 
 const char* pt_last_error(pt_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -414,6 +567,7 @@ int pt_create(int device_index, pt_handle* out) {
     if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
     if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
+    if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
     *out = h;
     return 0;
 }
@@ -425,6 +579,8 @@ int pt_destroy(pt_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
     (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters);
+    (void)hipFree(h->d_cell_start); (void)hipFree(h->d_items); (void)hipFree(h->d_item_ids);
+    (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -459,23 +615,12 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
     }
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    const int n_pad = (n + 3) & ~3;
-    std::vector<float> scan(size_t(n_pad + 8) * 4);    // + two quads that the pipelined loads may touch
+    std::vector<int> all(n);
+    for (int i = 0; i < n; ++i) all[i] = i;
+    int n_pad = 0;
+    std::vector<float> scan = scan_records(all, cx, cy, cz, r, &n_pad);
     std::vector<GeomRec> geom(n);
     std::vector<MatRec> mat(n);
-    for (int i = 0; i < n_pad + 8; ++i) {
-        float* rec = scan.data() + 8 * (i >> 1) + (i & 1);
-        if (i < n) {
-            rec[0] = float(cx[i]); rec[2] = float(cy[i]); rec[4] = float(cz[i]);
-            // -K from the float centre the scan multiplies with, so that b*b + 2 o.c - |o|^2 - K is
-            // the discriminant of the sphere tier 1 actually sees; r^2 in double.
-            const double fx = rec[0], fy = rec[2], fz = rec[4];
-            rec[6] = float(r[i] * r[i] - (fx * fx + fy * fy + fz * fz));   // -K
-        } else {
-            rec[0] = rec[2] = rec[4] = 0.0f;
-            rec[6] = -1e30f;                     // -K: never flagged
-        }
-    }
     for (int i = 0; i < n; ++i) {
         geom[i] = GeomRec{cx[i], cy[i], cz[i], r[i], 1 / r[i], r[i] * r[i]};   // Sphere.cpp:9, :28
         MatRec m;
@@ -493,6 +638,27 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
     if ((rc = upload(h, &h->d_geom, geom))) return rc;
     if ((rc = upload(h, &h->d_mat, mat))) return rc;
     h->n = n; h->n_pad = n_pad; h->have_scene = true;
+    h->h_cx.assign(cx, cx + n); h->h_cy.assign(cy, cy + n); h->h_cz.assign(cz, cz + n); h->h_r.assign(r, r + n);
+    h->grid_ready = false;
+    if (h->accel == PT_ACCEL_GRID) return build_grid(h);
+    return 0;
+}
+
+int pt_set_accel(pt_handle h, int mode) {
+    if (!h) return PT_ERR_INVALID;
+    if (mode != PT_ACCEL_NONE && mode != PT_ACCEL_GRID) return fail(h, PT_ERR_INVALID, "pt_set_accel: unknown mode");
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    h->accel = mode;
+    if (mode == PT_ACCEL_GRID && h->have_scene && !h->grid_ready) return build_grid(h);
+    return 0;
+}
+
+int pt_accel_info(pt_handle h, int info[6], double* cell_edge) {
+    if (!h || !info) return PT_ERR_INVALID;
+    if (!h->grid_ready) return fail(h, PT_ERR_STATE, "pt_accel_info: no grid has been built (pt_set_accel(PT_ACCEL_GRID) and pt_set_scene first)");
+    for (int i = 0; i < 6; ++i) info[i] = h->grid_info[i];
+    if (cell_edge) *cell_edge = double(h->grid.cell);
     return 0;
 }
 
@@ -614,18 +780,23 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         P.inv_w1 = 1.0f / float(width - 1); P.inv_h1 = 1.0f / float(height - 1);
         P.cam = h->cam;
         P.scene = scene_dev(h);
+        const bool use_grid = h->accel == PT_ACCEL_GRID;
+        if (use_grid && !h->grid_ready) return fail(h, PT_ERR_STATE, "pt_render: the grid has not been built");
+        if (use_grid) P.grid = h->grid; else std::memset(&P.grid, 0, sizeof(P.grid));
         P.accum_fx = h->d_fx;
         P.ray_count = h->d_counters;
         P.job_counter = reinterpret_cast<unsigned int*>(h->d_counters + 1);
         P.n_jobs = int(jobs);
-        if (h->resident_waves <= 0) {
+        int& resident = use_grid ? h->resident_waves_grid : h->resident_waves;
+        if (resident <= 0) {
             int per_cu = 0;
-            PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, 64, 0));
+            if (use_grid) PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0));
+            else PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0));
             hipDeviceProp_t prop;
             PT_HIP(h, hipGetDeviceProperties(&prop, h->device));
-            h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
+            resident = std::max(1, per_cu) * prop.multiProcessorCount;
         }
-        const long long grid = std::min<long long>(jobs, (long long)h->resident_waves * h->grid_factor_pct / 100);
+        const long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
         const bool timed = h->ev_used + 2 <= 8192;
         if (timed && h->ev.size() < h->ev_used + 2) {
             hipEvent_t a, b;
@@ -633,7 +804,8 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
             h->ev.push_back(a); h->ev.push_back(b);
         }
         if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-        hipLaunchKernelGGL(k_render, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        if (use_grid) hipLaunchKernelGGL(k_render<1>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        else hipLaunchKernelGGL(k_render<0>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
         PT_HIP(h, hipGetLastError());
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     }
@@ -750,8 +922,16 @@ int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, 
     PT_ALLOC_COPY(bo, o, v3); PT_ALLOC_COPY(bd, d, v3);
     PT_ALLOC_COPY(bt, (void*)nullptr, n * sizeof(double)); PT_ALLOC_COPY(bi, (void*)nullptr, n * sizeof(int));
     PT_ALLOC_COPY(bp, (void*)nullptr, v3); PT_ALLOC_COPY(bn, (void*)nullptr, v3); PT_ALLOC_COPY(bf, (void*)nullptr, n * sizeof(int));
-    hipLaunchKernelGGL(k_scan, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), n, bo.as<double>(), bd.as<double>(), t_min,
-                       bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+    if (h->accel == PT_ACCEL_GRID) {
+        if (!h->grid_ready) return fail(h, PT_ERR_STATE, "pt_scan: the grid has not been built");
+        hipLaunchKernelGGL(k_scan<1>, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(),
+                           t_min, bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+    } else {
+        GridDev none;
+        std::memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(k_scan<0>, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), none, n, bo.as<double>(), bd.as<double>(),
+                           t_min, bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+    }
     PT_HIP(h, hipGetLastError());
     PT_COPY_BACK(t, bt, n * sizeof(double)); PT_COPY_BACK(idx, bi, n * sizeof(int));
     PT_COPY_BACK(p, bp, v3); PT_COPY_BACK(nrm, bn, v3); PT_COPY_BACK(front, bf, n * sizeof(int));

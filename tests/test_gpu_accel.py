@@ -1,0 +1,155 @@
+"""GPU (-m gpu): the optional grid search (pt_set_accel(PT_ACCEL_GRID)) against the oracle's
+closest-hit search over every sphere (HittableList.cpp:21-36), to the same bar as the linear scan, and against
+the linear scan of the same library on whole frames."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import check_scan, f32, spheres, vec_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gdev():
+    from path_tracer_amd import Device
+    d = Device(0)
+    d.set_accel(1)
+    yield d
+    d.close()
+
+
+def both(gdev, orc, sc, o, d, allow=2, t_min=0.001, far=False):
+    gdev.set_scene(sc)
+    hs = orc.scene_create(sc)
+    ref = orc.scan(hs, o, d, t_min)
+    out = gdev.scan(o, d, t_min)
+    orc.scene_free(hs)
+    if not far:
+        check_scan(out, ref, allow_mismatch=allow)
+    else:
+        # Rays that start hundreds of units away: an fp32 direction places the hit point to ~|o| * 6e-8, which
+        # a sphere of radius 0.1 turns into a few 1e-4 of normal. Index, t and point keep the 1e-4 bar.
+        mism = out["idx"] != ref["idx"]
+        assert mism.sum() <= allow, mism.sum()
+        hit = ~mism & (ref["idx"] >= 0)
+        assert hit.sum() > 0.5 * len(hit)
+        assert (np.abs(out["t"][hit] - ref["t"][hit]) / ref["t"][hit]).max() < 1e-4
+        assert vec_rel_err(out["p"][hit], ref["p"][hit]).max() < 1e-4
+        assert np.abs(out["n"][hit] - ref["n"][hit]).max() < 2e-3
+        assert (out["front"][hit] != ref["front"][hit]).sum() == 0
+    return out, ref
+
+
+def test_grid_scan_500_spheres(gdev, orc):
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    rng = np.random.default_rng(7)
+    n = 20000
+    o = f32(np.stack([rng.uniform(-10, 10, n), rng.uniform(0.5, 6, n), rng.uniform(-10, 10, n)], axis=1))
+    d = rng.normal(size=(n, 3))
+    d[:, 1] = -np.abs(d[:, 1])
+    d = f32(d * rng.uniform(0.05, 12, size=(n, 1)))
+    out, ref = both(gdev, orc, sc, o, d)
+    info = gdev.accel_info()
+    assert info["big"] == 1 and info["entries"] >= 504 and min(info["dims"]) >= 1        # the ground sphere alone is "big"
+    # secondary rays: from just above the surfaces in every direction, and from far outside the grid box
+    sel = ref["idx"] >= 0
+    p0 = f32(ref["p"][sel] + 1e-3 * ref["n"][sel])
+    d1 = f32(rng.normal(size=p0.shape))
+    both(gdev, orc, sc, p0, d1)
+    far = f32(np.stack([rng.uniform(-300, 300, 4000), rng.uniform(0.01, 40, 4000), rng.uniform(-300, 300, 4000)], axis=1))
+    aim = f32(np.stack([rng.uniform(-10, 10, 4000), rng.uniform(0, 0.5, 4000), rng.uniform(-10, 10, 4000)], axis=1))
+    both(gdev, orc, sc, far, f32(aim - far), allow=6, far=True)
+    # axis-parallel and grazing directions (zero components in the walk)
+    ax = np.array([[1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1], [0, -1, 0], [0, 1, 0], [1, 0, 1], [1, -1e-9, 0]], dtype=np.float64)
+    oa = f32(np.stack([rng.uniform(-9, 9, 4000), rng.uniform(0.05, 0.6, 4000), rng.uniform(-9, 9, 4000)], axis=1))
+    both(gdev, orc, sc, oa, ax[rng.integers(0, len(ax), 4000)], allow=4)
+
+
+def test_grid_scan_and_frame_10k_spheres(gdev, dev, orc):
+    """configs[4] through the grid: the scan against the oracle, a small frame against the oracle with the
+    same philox numbers, and a larger frame against the linear scan of the same library."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(10000, 1, 2, half_extent=45.0)
+    cam = host.camera_setup()
+    rng = np.random.default_rng(4)
+    n = 8000
+    o = f32(np.stack([rng.uniform(-40, 40, n), rng.uniform(0.5, 4, n), rng.uniform(-40, 40, n)], axis=1))
+    d = rng.normal(size=(n, 3)); d[:, 1] = -np.abs(d[:, 1]) * 0.3
+    both(gdev, orc, sc, o, f32(d), allow=3)
+    info = gdev.accel_info()
+    assert info["big"] >= 1 and info["entries"] >= 9000 and info["dims"][0] > 50 and info["dims"][2] > 50
+    gdev.set_camera(cam)
+    hs = orc.scene_create(sc)
+    img, rays = gdev.render_image(64, 36, 2, 50, seed=(2 << 32) | 1)
+    ref, _, ref_rays = orc.render(hs, cam, 64, 36, 0, 2, 50, mode=1, seed_a=1, seed_b=2, threads=os.cpu_count() or 1)
+    orc.scene_free(hs)
+    diff = np.abs(img - ref).max(axis=2) / 2
+    assert (diff > 2e-3).mean() < 0.03 and abs(rays - ref_rays) < 0.01 * ref_rays
+    # grid against linear scan, same seed: the paths are the same until a grazing decision differs
+    dev.set_scene(sc); dev.set_camera(cam)
+    a, ra = gdev.render_image(320, 180, 4, 50, seed=11)
+    b, rb = dev.render_image(320, 180, 4, 50, seed=11)
+    diff = np.abs(a - b).max(axis=2) / 4
+    assert (diff > 2e-3).mean() < 0.01 and abs(ra - rb) < 0.002 * rb
+    assert abs(float(a.mean()) - float(b.mean())) < 0.001 * float(b.mean())
+    a2, ra2 = gdev.render_image(320, 180, 4, 50, seed=11)
+    assert ra2 == ra and np.array_equal(a, a2)                       # integer sums: repeatable bit for bit
+
+
+def test_grid_edges(gdev, orc, dev):
+    import json
+    from conftest import GOLDEN
+    from path_tracer_amd import PtError
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        kat = json.load(f)
+    for name in ("sphere_hit", "sphere_hit_inside"):
+        k = kat[name]
+        gdev.set_scene(spheres([k["sphere"]]))
+        r = gdev.scan([k["ray"]["o"]], [k["ray"]["d"]])
+        assert r["idx"][0] == 0 and r["t"][0] == pytest.approx(k["t"], rel=1e-6) and r["front"][0] == k["front"]
+        assert np.allclose(r["p"][0], k["p"], atol=1e-5) and np.allclose(r["n"][0], k["n"], atol=1e-6)
+    k = kat["tie_goes_to_later_index"]
+    gdev.set_scene(spheres(k["spheres"]))
+    r = gdev.scan([k["ray"]["o"]], [k["ray"]["d"]])
+    assert r["idx"][0] == k["idx"] and r["t"][0] == pytest.approx(k["t"], rel=1e-6)
+    # duplicates of one small sphere among others: the last copy wins, whatever cell order finds first
+    lst = [{"c": [0.3 * i, 0, -6], "r": 0.2} for i in range(-8, 9)]
+    lst += [{"c": [0, 0, -6], "r": 0.2}] * 3
+    gdev.set_scene(spheres(lst))
+    r = gdev.scan([[0, 0, 0]], [[0, 0, -1]])
+    assert r["idx"][0] == len(lst) - 1
+    # a miss, a sphere behind the ray, t_min cutting the near root, an empty batch
+    gdev.set_scene(spheres([{"c": [0, 0, -5], "r": 1}]))
+    r = gdev.scan([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 0], [0, 0, 1], [0, 0, -1]])
+    assert list(r["idx"]) == [-1, -1, 0]
+    r = gdev.scan([[0, 0, 0]], [[0, 0, -1]], t_min=5.0)
+    assert r["idx"][0] == 0 and r["t"][0] == pytest.approx(6.0, rel=1e-6) and r["front"][0] == 0
+    assert len(gdev.scan(np.zeros((0, 3)), np.zeros((0, 3)))["idx"]) == 0
+    # small counts; mixed sizes (every sphere big, none big, half and half); a 3-D cloud rather than a plane
+    rng = np.random.default_rng(3)
+    for n, rmax in ((1, 1.0), (2, 1.0), (5, 1.0), (9, 1.0), (64, 0.3), (400, 0.25), (400, 3.0)):
+        lst = [{"c": list(rng.uniform(-6, 6, 3) + np.array([0, 0, -14])), "r": float(rng.uniform(0.05, rmax))} for _ in range(n)]
+        o = f32(rng.uniform(-1, 1, size=(2048, 3)))
+        d = f32(np.stack([rng.uniform(-0.6, 0.6, 2048), rng.uniform(-0.6, 0.6, 2048), -np.ones(2048)], axis=1))
+        both(gdev, orc, spheres(lst), o, d, allow=2)
+        # rays that start inside the cloud
+        o2 = f32(rng.uniform(-6, 6, size=(2048, 3)) + np.array([0, 0, -14]))
+        both(gdev, orc, spheres(lst), o2, f32(rng.normal(size=(2048, 3))), allow=2)
+    with pytest.raises(PtError):
+        gdev.set_accel(7)
+    # back to the full scan on the same handle: identical to a handle that never left it
+    from path_tracer_amd import host
+    sc = host.generate_scene(250, 1, 2)
+    cam = host.camera_setup()
+    gdev.set_scene(sc); gdev.set_camera(cam)
+    dev.set_scene(sc); dev.set_camera(cam)
+    gdev.set_accel(0)
+    a, ra = gdev.render_image(96, 54, 3, 50, seed=5)
+    b, rb = dev.render_image(96, 54, 3, 50, seed=5)
+    gdev.set_accel(1)
+    assert ra == rb and np.array_equal(a, b)
+    c, rc = gdev.render_image(96, 54, 3, 50, seed=5)
+    assert abs(rc - rb) < 0.005 * rb and (np.abs(c - b).max(axis=2) / 3 > 2e-3).mean() < 0.02

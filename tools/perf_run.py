@@ -7,7 +7,8 @@ from path_tracer_amd import Device, host
 n = int(os.environ.get("SPHERES", "500")); spp = int(os.environ.get("SPP", "100")); reps = int(os.environ.get("REPS", "3"))
 W, H = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080"))
 sc = host.generate_scene(n, 1, 2, half_extent=float(os.environ.get("EXTENT", "10")), diffuse_below=float(os.environ.get("DIFFUSE", "0.6")), metal_below=float(os.environ.get("METAL", "0.9"))); cam = host.camera_setup(aspect=W / H)
-dev = Device(0); dev.set_scene(sc); dev.set_camera(cam)
+dev = Device(0); dev.set_accel(int(os.environ.get("ACCEL", "0"))); dev.set_scene(sc); dev.set_camera(cam)
+if os.environ.get("ACCEL", "0") != "0": print("grid", dev.accel_info())
 img, rays = dev.render_image(200, 113, 16, 50, seed=7)
 print("hash", hashlib.sha1(img.tobytes()).hexdigest()[:16], "rays", rays, "mean", float(img.mean()) / 16)
 dev.kernel_times()
