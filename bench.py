@@ -73,6 +73,38 @@ def measured_traffic(default_workload):
         return None
 
 
+def extras(dev, host, accum, W, H, spp, depth, scene, cam):
+    """Outside the timed region and outside the roofline figure: the same workload with the optional grid search
+    (pt_set_accel), and configs[4] (10k spheres, 256 spp) once with each search."""
+    import torch
+
+    def kernel_ms(reps, s):
+        dev.kernel_times()
+        for _ in range(reps):
+            accum.zero_()
+            dev.render(W, H, 0, s, depth, 42, accum_ptr=accum.data_ptr())
+        torch.cuda.synchronize()
+        return float(np.min(dev.kernel_times()))
+
+    res = {"note": "kernel times (HIP events), best of the runs; not part of `value` or `roofline`"}
+    dev.set_accel(1)
+    kernel_ms(1, spp)
+    ms = kernel_ms(3, spp)
+    res["grid_search_same_workload"] = {"kernel_ms": ms, "Msamples_per_s": W * H * spp / ms / 1e3, "grid": dev.accel_info()}
+    big = host.generate_scene(10000, 1, 2, half_extent=45.0)
+    dev.set_scene(big)
+    ms_grid = kernel_ms(2, 256)
+    info = dev.accel_info()
+    dev.set_accel(0)
+    ms_scan = kernel_ms(1, 256)
+    res["configs4_10k_spheres_256spp"] = {"spheres": len(big["kind"]), "full_scan_kernel_ms": ms_scan, "grid_kernel_ms": ms_grid,
+                                          "full_scan_Msamples_per_s": W * H * 256 / ms_scan / 1e3,
+                                          "grid_Msamples_per_s": W * H * 256 / ms_grid / 1e3, "grid": info}
+    dev.set_scene(scene)
+    dev.set_camera(cam)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +116,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--spheres", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the grid-search and 10k-sphere lines (N=1 only)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control flow on ONE device: every rank renders on cuda:0 and the reduce goes "
                          "through gloo on host copies (RCCL refuses two ranks on one GPU); not a measurement")
@@ -190,10 +223,15 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS,
                          "traffic": measured_traffic((W, H, spp, depth, args.spheres) == (1920, 1080, 100, 50, 500)),
-                         "kernel": "k_render", "kernel_ms": k_ms,
+                         "kernel": "k_render<0>", "kernel_ms": k_ms,
                          "flops_per_launch": flops_per_launch,
                          "note": "algorithmic flops = rays x (17 x spheres + 60); rays counted by the kernel"},
         }
+        if world == 1 and not args.no_extras:
+            try:
+                out["extras"] = extras(dev, host, accum, W, H, spp, depth, scene, cam)
+            except Exception as e:                                   # never lose the headline line to an extra
+                out["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.spheres, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)

@@ -48,8 +48,8 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
     const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ta.x, tb.x), __builtin_fminf(ta.y, tb.y)),
                                        __builtin_fmaxf(__builtin_fminf(ta.z, tb.z), 0.0f));
     const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ta.x, tb.x), __builtin_fmaxf(ta.y, tb.y)),
-                                        __builtin_fminf(__builtin_fmaxf(ta.z, tb.z), best_t));
-    bool live = t_in <= t_out;
+                                        __builtin_fmaxf(ta.z, tb.z));   // far side of the box
+    bool live = (t_in <= t_out) & (t_in <= best_t);
 
     // ---- the cell the ray enters at, the distance to the next cell wall on each axis ----
     const f3 q = (fma3(dh, t_in, o) - G.gmin) * G.inv_cell;
@@ -61,42 +61,59 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
     float tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), G.cell, G.gmin.y) - o.y) * inv.y;
     float tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), G.cell, G.gmin.z) - o.z) * inv.z;
     const float tdx = G.cell * __builtin_fabsf(inv.x), tdy = G.cell * __builtin_fabsf(inv.y), tdz = G.cell * __builtin_fabsf(inv.z);
-    int rx = fx ? G.nx - 1 - ix : ix, ry = fy ? G.ny - 1 - iy : iy, rz = fz ? G.nz - 1 - iz : iz;   // cells left on each axis
     const int sx = fx ? 1 : -1, sy = fy ? G.nx : -G.nx, sz = fz ? G.nx * G.ny : -(G.nx * G.ny);
+    const int last_cell = G.nx * G.ny * G.nz - 1;
     int ci = (iz * G.ny + iy) * G.nx + ix;
 
+    // One pass of the loop below either tests one entry of the current cell or moves to the next cell, chosen
+    // per lane with selects so that the wave runs one instruction stream without branches. The entry of this
+    // pass and the cell range of the next are requested together: one memory round trip per pass.
+    // A lane leaves when its closest hit lies before the exit of its cell, or at the far side of the box
+    // (t_box; should rounding let it take one more step, the cell index is clamped to the table: a cell too many
+    // is looked at, which cannot change the answer, and the next exit distance lies beyond the box for certain).
+    // Every pass consumes an entry or moves one cell on: at most nx + ny + nz + 3 + entries passes.
     uint32_t k = 0, kend = 0;
     if (live) { k = G.cell_start[ci]; kend = G.cell_start[ci + 1]; }
-    // Every pass of this loop either consumes one entry of the current cell or moves one cell along one
-    // axis, and a lane leaves when an axis runs out of cells: at most nx + ny + nz + entries passes.
-    while (live) {
-        if (k < kend) {
-            const float4 s = G.items[k];
+    while (__builtin_amdgcn_ballot_w64(live)) {
+#ifdef PT_STATS
+        {   // passes of the wave, lanes still walking, lanes with an entry to test
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(live), hm = __builtin_amdgcn_ballot_w64(live && k < kend);
+            if (threadIdx.x == 0) { atomicAdd(&g_stats[5], 1ull); atomicAdd(&g_stats[6], (unsigned long long)__popcll(lm)); atomicAdd(&g_stats[7], (unsigned long long)__popcll(hm)); }
+        }
+#endif
+        if (live) {
+            const bool has = k < kend;
+            const float4 s = G.items[k];                  // one entry past the last is allocated: k == kend is readable
             const int id = G.ids[k];
-            ++k;
+            // -- the step, for the lanes whose cell is used up --
+            const float t_exit = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
+            const bool stop = !has & ((best_t < t_exit) | (t_exit >= t_out));
+            const bool st = !has & !stop;
+            const bool ax = (tmx <= tmy) & (tmx <= tmz), ay = !ax & (tmy <= tmz);
+            const bool mx = st & ax, my = st & ay, mz = st & !ax & !ay;
+            tmx += mx ? tdx : 0.0f;
+            tmy += my ? tdy : 0.0f;
+            tmz += mz ? tdz : 0.0f;
+            ci += mx ? sx : (my ? sy : (mz ? sz : 0));
+            ci = min(max(ci, 0), last_cell);
+            const uint32_t r0 = G.cell_start[ci], r1 = G.cell_start[ci + 1];
+            // -- the test, for the lanes with an entry: Sphere.cpp:6-19 relative to the ray origin --
             const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);                  // Sphere.cpp:6 (sign folded into b)
             const float b = dot(oc, dh);                                          // :8
             // disc = r^2 - (distance from the centre to the ray's line)^2, from the perpendicular part of oc:
             // b*b - |oc|^2 cancels badly once the sphere is far away compared with its radius
             const f3 perp = fma3(dh, -b, oc);
             const float T = __builtin_fmaf(-perp.z, perp.z, __builtin_fmaf(-perp.y, perp.y, __builtin_fmaf(-perp.x, perp.x, s.w)));   // :9-10
-            const float sq = fast_sqrt(T);                                        // NaN for T < 0: compares below are false
+            const float sq = fast_sqrt(T);                                        // NaN for T < 0: t is NaN, the compares below false
             const float t1 = b - sq, t2 = b + sq;
             const float t = (t1 >= tmin) ? t1 : t2;                               // :17-19
             const bool closer = (t < best_t) | ((t == best_t) & (id > best_i));   // HittableList.cpp:28-31: later index wins ties
-            const bool ok = (T >= 0.0f) & (id != prev) & (t >= tmin) & closer;
+            const bool ok = has & (id != prev) & (t >= tmin) & closer;
             best_t = ok ? t : best_t;
             best_i = ok ? id : best_i;
-        } else {
-            const float t_exit = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
-            if (best_t < t_exit) break;                   // the closest hit lies inside the cells already walked
-            int left;
-            if (tmx <= tmy && tmx <= tmz) { tmx += tdx; ci += sx; left = --rx; }
-            else if (tmy <= tmz)          { tmy += tdy; ci += sy; left = --ry; }
-            else                          { tmz += tdz; ci += sz; left = --rz; }
-            if (left < 0 || t_exit > t_out) break;        // out of the grid
-            k = G.cell_start[ci];
-            kend = G.cell_start[ci + 1];
+            k = has ? k + 1 : r0;
+            kend = has ? kend : r1;
+            live = !stop;
         }
     }
 

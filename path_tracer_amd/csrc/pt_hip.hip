@@ -357,6 +357,7 @@ struct pt_context {
     GridDev grid;
     int grid_info[6] = {0, 0, 0, 0, 0, 0};     // nx, ny, nz, spheres in the big list, entries, fullest cell
     double grid_cell_scale = 4.0;              // cell edge = scale x median radius (PT_GRID_CELL_SCALE)
+    double grid_big_ratio = 3.0;               // radius above ratio x median: big list (PT_GRID_BIG_RATIO)
     int resident_waves_grid = 0;
     CameraDev cam;
     // frame
@@ -435,7 +436,8 @@ static std::vector<float> scan_records(const std::vector<int>& which, const doub
 }
 
 // The uniform grid of pt_grid.h from the host copy of the geometry. Cell edge = grid_cell_scale x the
-// median radius; a sphere whose box would span more than four cells on an axis goes to the big list.
+// median radius; a sphere much larger than the median (grid_big_ratio), or whose box would span more than
+// four cells on an axis, goes to the big list: it would stretch the box of the grid and fill many cells.
 static int build_grid(pt_handle h) {
     const int n = h->n;
     const double *cx = h->h_cx.data(), *cy = h->h_cy.data(), *cz = h->h_cz.data(), *r = h->h_r.data();
@@ -447,7 +449,7 @@ static int build_grid(pt_handle h) {
     int dims[3];
     for (int attempt = 0;; ++attempt) {
         big.clear(); small.clear();
-        for (int i = 0; i < n; ++i) (2.0 * r[i] > 3.0 * cell ? big : small).push_back(i);
+        for (int i = 0; i < n; ++i) ((r[i] > h->grid_big_ratio * rs[n / 2] || 2.0 * r[i] > 3.0 * cell) ? big : small).push_back(i);
         for (int a = 0; a < 3; ++a) { lo[a] = 0; hi[a] = 0; }
         bool first = true;
         for (int i : small) {
@@ -514,7 +516,7 @@ static int build_grid(pt_handle h) {
     for (size_t b = 0; b < big.size(); ++b) big_local[big[b]] = int(b);
     int big_pad = 0;
     std::vector<float> big_scan = scan_records(big, cx, cy, cz, r, &big_pad);
-    if (items.empty()) { items.push_back(float4{0, 0, 0, 0}); ids.push_back(0); }   // never read: no cell points at it
+    items.push_back(float4{0, 0, 0, -1.0f}); ids.push_back(0);   // the walk reads one entry past a cell's last (and drops it)
     std::vector<int> big_ids(big);
     if (big_ids.empty()) big_ids.push_back(0);
     int rc;
@@ -568,6 +570,7 @@ int pt_create(int device_index, pt_handle* out) {
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
     if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
+    if (const char* br = std::getenv("PT_GRID_BIG_RATIO")) { double v = std::atof(br); if (v >= 1 && v < 1e6) h->grid_big_ratio = v; }
     *out = h;
     return 0;
 }
@@ -822,6 +825,8 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         PT_HIP(h, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stats), sizeof(st)));
         fprintf(stderr, "[pt stats] wave_segments %llu live_lanes %llu (%.3f of 64) quads %llu tier2_quads %llu (%.4f) tier2_lanes %llu\n",
                 st[0], st[1], st[0] ? double(st[1]) / st[0] / 64 : 0.0, st[2], st[3], st[2] ? double(st[3]) / st[2] : 0.0, st[4]);
+        if (st[5]) fprintf(stderr, "[pt stats] grid passes %llu (%.2f per wave segment) walking lanes %.3f of 64, lanes testing an entry %.3f of 64\n",
+                           st[5], st[0] ? double(st[5]) / st[0] : 0.0, double(st[6]) / st[5], double(st[7]) / st[5]);
         unsigned long long z[8] = {0};
         PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)));
     }

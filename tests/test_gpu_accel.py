@@ -53,7 +53,7 @@ def test_grid_scan_500_spheres(gdev, orc):
     d = f32(d * rng.uniform(0.05, 12, size=(n, 1)))
     out, ref = both(gdev, orc, sc, o, d)
     info = gdev.accel_info()
-    assert info["big"] == 1 and info["entries"] >= 504 and min(info["dims"]) >= 1        # the ground sphere alone is "big"
+    assert 1 <= info["big"] <= 5 and info["entries"] >= 500 and min(info["dims"]) >= 1        # the ground sphere and the large fixed spheres are "big"
     # secondary rays: from just above the surfaces in every direction, and from far outside the grid box
     sel = ref["idx"] >= 0
     p0 = f32(ref["p"][sel] + 1e-3 * ref["n"][sel])

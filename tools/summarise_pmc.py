@@ -4,16 +4,25 @@ import collections, csv, glob, json, os, sys
 tag = sys.argv[1]
 root = os.path.join(os.path.dirname(__file__), "..")
 out = {"kernels": {}, "counters": {}}
+
+
+def norm(name):
+    """'void k_render<0>(RenderParams)' -> 'k_render' (the full-scan sample loop); the grid variant keeps its '<1>'."""
+    name = name.split("(")[0].replace("void ", "").strip()
+    return "k_render" if name == "k_render<0>" else name
+
+
+
 for f in glob.glob(os.path.join(root, "gpurun_out", tag + "_stats", "*", "*kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
-        out["kernels"][row["Name"].split("(")[0]] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
+        out["kernels"][norm(row["Name"])] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
                                                       "min_ms": float(row["MinNs"]) / 1e6, "max_ms": float(row["MaxNs"]) / 1e6,
                                                       "percent": float(row["Percentage"])}
 for d in glob.glob(os.path.join(root, "gpurun_out", tag + "_pmc*")):
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0]
+            k = norm(row["Kernel_Name"])
             if k.startswith("k_"):
                 agg[(k, row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in agg.items():
