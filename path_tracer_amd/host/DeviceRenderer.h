@@ -38,6 +38,9 @@ public:
         world.describe(flat, mats);
         DeviceSession::instance().uploadScene(m_handle, flat);
     }
+    // Closest-hit search: false = every sphere for every ray (HittableList.cpp:27, the default), true = the
+    // uniform grid of pt_set_accel (same answer, far fewer tests in scenes of thousands of spheres).
+    void setGridSearch(bool on) { check(pt_set_accel(m_handle, on ? PT_ACCEL_GRID : PT_ACCEL_NONE), "pt_set_accel"); }
     void setCamera(const Camera& camera) {
         double c[19];
         camera.deviceConstants(c);

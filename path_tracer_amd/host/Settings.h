@@ -35,6 +35,7 @@ struct Settings {
     double sceneHalfExtent = 10.0;
     int numberOfGPUs = 1;
     bool binaryOutput = false;        // outputFormat = P6 (the reference writes ASCII P3)
+    bool gridSearch = false;          // closestHitSearch = grid (the reference tests every sphere: "scan")
 
     int imageHeight() const { return static_cast<int>(imageWidth / imageAspectRatio); }   // Path Tracer.cpp:176
 };
@@ -62,6 +63,7 @@ inline Settings readSettings(ConfigReader& config, std::ostream* log = nullptr) 
         if (config.contains("sceneHalfExtent")) s.sceneHalfExtent = config.readValue("sceneHalfExtent", s.sceneHalfExtent);
         if (config.contains("numberOfGPUs")) s.numberOfGPUs = config.readValue("numberOfGPUs", s.numberOfGPUs);
         if (config.contains("outputFormat")) s.binaryOutput = config.readValue("outputFormat") == "P6";
+        if (config.contains("closestHitSearch")) s.gridSearch = config.readValue("closestHitSearch") == "grid";
         config.clear();
         if (log) *log << "All values read from file correctly.\n";
     } catch (ConfigReader::ConfigException& except) {

@@ -176,6 +176,7 @@ long pth_render_ppm(const char* config_text, char* out, long cap, double* msampl
         opt.numberOfSpheres = s.numberOfSpheres; opt.seedA = s.sceneSeedA; opt.seedB = s.sceneSeedB; opt.halfExtent = s.sceneHalfExtent;
         dp::addRandomSpheres(world, opt);
         dp::DeviceRenderer dev(0);
+        dev.setGridSearch(s.gridSearch);
         dev.setWorld(world); dev.setCamera(camera);
         const int w = s.imageWidth, h = s.imageHeight();
         dev.begin(w, h);

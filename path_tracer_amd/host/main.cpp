@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
         std::vector<std::unique_ptr<dp::DeviceRenderer>> devs;
         for (int g = 0; g < gpus; ++g) {
             devs.push_back(std::make_unique<dp::DeviceRenderer>(g));
+            devs.back()->setGridSearch(s.gridSearch);
             devs.back()->setWorld(world);
             devs.back()->setCamera(camera);
             devs.back()->begin(width, height);

@@ -84,3 +84,7 @@ def test_whole_frame_through_the_host_classes(orc):
     assert got.shape == ref.shape
     assert (np.abs(got - ref) > 1).mean() < 0.03
     assert abs(got.mean() - ref.mean()) < 0.5
+    # the optional key of this build: the same frame with the grid search
+    ppm2, _ = host.render_ppm(cfg + "closestHitSearch = grid\n")
+    got2 = np.array([[int(v) for v in ln.split()] for ln in ppm2.decode().split("\n")[3:3 + 64 * 36]])
+    assert (np.abs(got2 - got) > 1).mean() < 0.01
