@@ -33,13 +33,30 @@ struct GridDev {
 
 PT_DEV float nonzero(float d) { return __builtin_fabsf(d) < 1e-12f ? __builtin_copysignf(1e-12f, d) : d; }
 
-// Same contract as scan_spheres (pt_device.h): best_i is a LIST index.
-PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
-    // ---- the big list, through the scalar-register scan; its indices are positions in that list ----
+// A walk in progress, per lane.
+struct GridWalk {
+    float tmx, tmy, tmz;          // distance along the ray to the next cell wall on each axis
+    float tdx, tdy, tdz;          // distance between walls
+    float t_out;                  // far side of the box
+    float tmin;
+    float best_t;                 // closest hit so far (starts as the big list's)
+    int best_i;
+    int ci, sx, sy, sz;           // cell index and its step on each axis
+    uint32_t k, kend;             // entries of the current cell still to test
+    bool prev_in_grid;            // the sphere the ray starts on lives in the grid (else the big list handled it)
+    bool live;
+};
+
+// Starts the search for one ray: scans the big list (scalar-register scan; its indices are positions in that
+// list), clips the ray to the box of the grid and sets up the walk. o, dh, tmin, prev, self_t as scan_spheres.
+PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float self_t, GridWalk& w) {
     int prev_local = -1;
     if (prev >= 0) prev_local = G.big_local[prev];
+    float best_t; int best_i;
     scan_spheres(G.big, o, dh, tmin, prev_local, self_t, best_t, best_i);
     if (best_i >= 0) best_i = G.big_ids[best_i];
+    w.best_t = best_t; w.best_i = best_i; w.tmin = tmin;
+    w.prev_in_grid = (prev >= 0) & (prev_local < 0);
 
     // ---- clip the ray to the box of the grid ----
     const f3 dn = mk3(nonzero(dh.x), nonzero(dh.y), nonzero(dh.z));   // the walk only: a zero component would make 0 * inf
@@ -47,9 +64,9 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
     const f3 ta = (G.gmin - o) * inv, tb = (G.gmax - o) * inv;
     const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ta.x, tb.x), __builtin_fminf(ta.y, tb.y)),
                                        __builtin_fmaxf(__builtin_fminf(ta.z, tb.z), 0.0f));
-    const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ta.x, tb.x), __builtin_fmaxf(ta.y, tb.y)),
-                                        __builtin_fmaxf(ta.z, tb.z));   // far side of the box
-    bool live = (t_in <= t_out) & (t_in <= best_t);
+    w.t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ta.x, tb.x), __builtin_fmaxf(ta.y, tb.y)),
+                              __builtin_fmaxf(ta.z, tb.z));   // far side of the box
+    w.live = (t_in <= w.t_out) & (t_in <= best_t);
 
     // ---- the cell the ray enters at, the distance to the next cell wall on each axis ----
     const f3 q = (fma3(dh, t_in, o) - G.gmin) * G.inv_cell;
@@ -57,72 +74,82 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
     const int iy = min(max(int(__builtin_floorf(q.y)), 0), G.ny - 1);
     const int iz = min(max(int(__builtin_floorf(q.z)), 0), G.nz - 1);
     const bool fx = dn.x > 0.0f, fy = dn.y > 0.0f, fz = dn.z > 0.0f;
-    float tmx = (__builtin_fmaf(float(ix + (fx ? 1 : 0)), G.cell, G.gmin.x) - o.x) * inv.x;
-    float tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), G.cell, G.gmin.y) - o.y) * inv.y;
-    float tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), G.cell, G.gmin.z) - o.z) * inv.z;
-    const float tdx = G.cell * __builtin_fabsf(inv.x), tdy = G.cell * __builtin_fabsf(inv.y), tdz = G.cell * __builtin_fabsf(inv.z);
-    const int sx = fx ? 1 : -1, sy = fy ? G.nx : -G.nx, sz = fz ? G.nx * G.ny : -(G.nx * G.ny);
-    const int last_cell = G.nx * G.ny * G.nz - 1;
-    int ci = (iz * G.ny + iy) * G.nx + ix;
+    w.tmx = (__builtin_fmaf(float(ix + (fx ? 1 : 0)), G.cell, G.gmin.x) - o.x) * inv.x;
+    w.tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), G.cell, G.gmin.y) - o.y) * inv.y;
+    w.tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), G.cell, G.gmin.z) - o.z) * inv.z;
+    w.tdx = G.cell * __builtin_fabsf(inv.x); w.tdy = G.cell * __builtin_fabsf(inv.y); w.tdz = G.cell * __builtin_fabsf(inv.z);
+    w.sx = fx ? 1 : -1; w.sy = fy ? G.nx : -G.nx; w.sz = fz ? G.nx * G.ny : -(G.nx * G.ny);
+    w.ci = (iz * G.ny + iy) * G.nx + ix;
+    w.k = 0; w.kend = 0;
+    if (w.live) { w.k = G.cell_start[w.ci]; w.kend = G.cell_start[w.ci + 1]; }
+}
 
-    // One pass of the loop below either tests one entry of the current cell or moves to the next cell, chosen
-    // per lane with selects so that the wave runs one instruction stream without branches. The entry of this
-    // pass and the cell range of the next are requested together: one memory round trip per pass.
-    // A lane leaves when its closest hit lies before the exit of its cell, or at the far side of the box
-    // (t_box; should rounding let it take one more step, the cell index is clamped to the table: a cell too many
-    // is looked at, which cannot change the answer, and the next exit distance lies beyond the box for certain).
-    // Every pass consumes an entry or moves one cell on: at most nx + ny + nz + 3 + entries passes.
-    uint32_t k = 0, kend = 0;
-    if (live) { k = G.cell_start[ci]; kend = G.cell_start[ci + 1]; }
-    while (__builtin_amdgcn_ballot_w64(live)) {
+// One pass of a live walk: either tests one entry of the current cell or moves to the next cell, chosen with
+// selects so that the lanes of a wave run one instruction stream. The entry of this pass and the cell range
+// of the next are requested together: one memory round trip per pass.
+// A lane leaves (live = false) when its closest hit lies before the exit of its cell, or at the far side of
+// the box (should rounding let it take one more step, the cell index is clamped to the table: a cell too many
+// is looked at, which cannot change the answer, and the next exit distance lies beyond the box for certain).
+// Every pass consumes an entry or moves one cell on: at most nx + ny + nz + 3 + entries passes per walk.
+PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
+    const bool has = w.k < w.kend;
+    const float4 s = G.items[w.k];                    // one entry past the last is allocated: k == kend is readable
+    const int id = G.ids[w.k];
+    // -- the step, for the lanes whose cell is used up --
+    const float t_exit = __builtin_fminf(__builtin_fminf(w.tmx, w.tmy), w.tmz);
+    const bool stop = !has & ((w.best_t < t_exit) | (t_exit >= w.t_out));
+    const bool st = !has & !stop;
+    const bool ax = (w.tmx <= w.tmy) & (w.tmx <= w.tmz), ay = !ax & (w.tmy <= w.tmz);
+    const bool mx = st & ax, my = st & ay, mz = st & !ax & !ay;
+    w.tmx += mx ? w.tdx : 0.0f;
+    w.tmy += my ? w.tdy : 0.0f;
+    w.tmz += mz ? w.tdz : 0.0f;
+    int ci = w.ci + (mx ? w.sx : (my ? w.sy : (mz ? w.sz : 0)));
+    ci = min(max(ci, 0), G.nx * G.ny * G.nz - 1);
+    w.ci = ci;
+    const uint32_t r0 = G.cell_start[ci], r1 = G.cell_start[ci + 1];
+    // -- the test, for the lanes with an entry: Sphere.cpp:6-19 relative to the ray origin --
+    const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);                  // Sphere.cpp:6 (sign folded into b)
+    const float b = dot(oc, dh);                                          // :8
+    // disc = r^2 - (distance from the centre to the ray's line)^2, from the perpendicular part of oc:
+    // b*b - |oc|^2 cancels badly once the sphere is far away compared with its radius
+    const f3 perp = fma3(dh, -b, oc);
+    const float T = __builtin_fmaf(-perp.z, perp.z, __builtin_fmaf(-perp.y, perp.y, __builtin_fmaf(-perp.x, perp.x, s.w)));   // :9-10
+    const float sq = fast_sqrt(T);                                        // NaN for T < 0: t is NaN, the compares below false
+    const float t1 = b - sq, t2 = b + sq;
+    const float t = (t1 >= w.tmin) ? t1 : t2;                             // :17-19
+    const bool closer = (t < w.best_t) | ((t == w.best_t) & (id > w.best_i));   // HittableList.cpp:28-31: later index wins ties
+    const bool ok = has & (id != prev) & (t >= w.tmin) & closer;
+    w.best_t = ok ? t : w.best_t;
+    w.best_i = ok ? id : w.best_i;
+    w.k = has ? w.k + 1 : r0;
+    w.kend = has ? w.kend : r1;
+    w.live = !stop;
+}
+
+// The answer of a finished walk. The sphere the ray starts on, when it lives in the grid: its near root is the
+// start point, its far root (self_t) counts when the ray heads into the sphere (see scan_spheres).
+PT_DEV void grid_end(const GridWalk& w, int prev, float self_t, float& best_t, int& best_i) {
+    const bool ok = w.prev_in_grid & (self_t >= w.tmin) & (self_t <= w.best_t);
+    best_t = ok ? self_t : w.best_t;
+    best_i = ok ? prev : w.best_i;
+}
+
+// Same contract as scan_spheres (pt_device.h): best_i is a LIST index. The whole search for one ray per lane;
+// the wave stays in the loop until its last lane is done (the sample loop interleaves walks instead).
+PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+    GridWalk w;
+    grid_begin(G, o, dh, tmin, prev, self_t, w);
+    while (__builtin_amdgcn_ballot_w64(w.live)) {
 #ifdef PT_STATS
         {   // passes of the wave, lanes still walking, lanes with an entry to test
-            const unsigned long long lm = __builtin_amdgcn_ballot_w64(live), hm = __builtin_amdgcn_ballot_w64(live && k < kend);
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(w.live), hm = __builtin_amdgcn_ballot_w64(w.live && w.k < w.kend);
             if (threadIdx.x == 0) { atomicAdd(&g_stats[5], 1ull); atomicAdd(&g_stats[6], (unsigned long long)__popcll(lm)); atomicAdd(&g_stats[7], (unsigned long long)__popcll(hm)); }
         }
 #endif
-        if (live) {
-            const bool has = k < kend;
-            const float4 s = G.items[k];                  // one entry past the last is allocated: k == kend is readable
-            const int id = G.ids[k];
-            // -- the step, for the lanes whose cell is used up --
-            const float t_exit = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
-            const bool stop = !has & ((best_t < t_exit) | (t_exit >= t_out));
-            const bool st = !has & !stop;
-            const bool ax = (tmx <= tmy) & (tmx <= tmz), ay = !ax & (tmy <= tmz);
-            const bool mx = st & ax, my = st & ay, mz = st & !ax & !ay;
-            tmx += mx ? tdx : 0.0f;
-            tmy += my ? tdy : 0.0f;
-            tmz += mz ? tdz : 0.0f;
-            ci += mx ? sx : (my ? sy : (mz ? sz : 0));
-            ci = min(max(ci, 0), last_cell);
-            const uint32_t r0 = G.cell_start[ci], r1 = G.cell_start[ci + 1];
-            // -- the test, for the lanes with an entry: Sphere.cpp:6-19 relative to the ray origin --
-            const f3 oc = mk3(s.x - o.x, s.y - o.y, s.z - o.z);                  // Sphere.cpp:6 (sign folded into b)
-            const float b = dot(oc, dh);                                          // :8
-            // disc = r^2 - (distance from the centre to the ray's line)^2, from the perpendicular part of oc:
-            // b*b - |oc|^2 cancels badly once the sphere is far away compared with its radius
-            const f3 perp = fma3(dh, -b, oc);
-            const float T = __builtin_fmaf(-perp.z, perp.z, __builtin_fmaf(-perp.y, perp.y, __builtin_fmaf(-perp.x, perp.x, s.w)));   // :9-10
-            const float sq = fast_sqrt(T);                                        // NaN for T < 0: t is NaN, the compares below false
-            const float t1 = b - sq, t2 = b + sq;
-            const float t = (t1 >= tmin) ? t1 : t2;                               // :17-19
-            const bool closer = (t < best_t) | ((t == best_t) & (id > best_i));   // HittableList.cpp:28-31: later index wins ties
-            const bool ok = has & (id != prev) & (t >= tmin) & closer;
-            best_t = ok ? t : best_t;
-            best_i = ok ? id : best_i;
-            k = has ? k + 1 : r0;
-            kend = has ? kend : r1;
-            live = !stop;
-        }
+        if (w.live) grid_pass(G, o, dh, prev, w);
     }
-
-    // ---- the sphere the ray starts on, when it lives in the grid (the big list handled its own) ----
-    {
-        const bool ok = (prev >= 0) & (prev_local < 0) & (self_t >= tmin) & (self_t <= best_t);
-        best_t = ok ? self_t : best_t;
-        best_i = ok ? prev : best_i;
-    }
+    grid_end(w, prev, self_t, best_t, best_i);
 }
 
 }   // namespace ptd

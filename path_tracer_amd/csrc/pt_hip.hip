@@ -89,7 +89,10 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #define PT_WAVES_PER_EU 6
 #endif
 #ifndef PT_GRID_WAVES_PER_EU
-#define PT_GRID_WAVES_PER_EU 8      // the grid walk waits on memory: more waves to switch between
+#define PT_GRID_WAVES_PER_EU 6      // 80 registers: at 8 waves (64) the walk state spills and the kernel runs at half the speed
+#endif
+#ifndef PT_GRID_RATIO
+#define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER_EU) k_render(const RenderParams P) {
@@ -114,6 +117,12 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     int slot = 0, bounce = 0, prev = -1, lbank = 0;
     uint32_t pixel = 0, sample = 0;
 
+    // MODE 1 only: the walk through the grid of this lane's ray, and whether its answer waits to be used
+    GridWalk gw;
+    gw.tmx = gw.tmy = gw.tmz = gw.tdx = gw.tdy = gw.tdz = gw.t_out = gw.tmin = gw.best_t = 0.0f;
+    gw.best_i = -1; gw.ci = gw.sx = gw.sy = gw.sz = 0; gw.k = gw.kend = 0u; gw.prev_in_grid = false; gw.live = false;
+    bool walking = false, pending = false;
+
     // One iteration = one ray of every live path: scan, then either the sky (path ends) or the hit
     // record; lanes whose path ended take a new (sample, pixel) item; ONE philox block per lane then
     // feeds either the camera ray of a new path (bounce 0) or the scatter of a continuing one.
@@ -121,11 +130,29 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
         HitRec h;
         MatRec mat;
         bool hit = false;
-        if (active) {
+        if constexpr (MODE == 1) {
+            // Walks differ in length from lane to lane. Rather than wait for the longest, the wave walks until
+            // at most a quarter of its rays are still on their way, handles the answers of the others (below),
+            // gives those lanes their next rays and comes back here; the walks still in progress simply go on.
+            for (;;) {
+                const int nw = __popcll(__builtin_amdgcn_ballot_w64(walking)), np = __popcll(__builtin_amdgcn_ballot_w64(pending));
+                if (nw * PT_GRID_RATIO <= np) break;
+#ifdef PT_STATS
+                { const int nh = __popcll(__builtin_amdgcn_ballot_w64(walking && gw.k < gw.kend));
+                  PT_STAT_ADD(5, 1); PT_STAT_ADD(6, nw); PT_STAT_ADD(7, nh); }
+#endif
+                if (walking) {
+                    grid_pass(P.grid, o, dh, prev, gw);
+                    if (!gw.live) { walking = false; pending = true; }
+                }
+            }
+        }
+        const bool answered = MODE == 0 ? active : pending;      // lanes whose ray has (MODE 0: gets now) its closest hit
+        if (answered) {
             ++rays;
             float bt; int bi;
             if constexpr (MODE == 0) scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            else scan_grid(P.grid, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            else { grid_end(gw, prev, self_t, bt, bi); pending = false; }
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 unsigned long long* a = acc + 192 * lbank + slot * 3;
@@ -191,12 +218,12 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             if (no_more_jobs) break;
             continue;
         }
-        { const int live = __popcll(__ballot(active)); (void)live;
+        { const int live = __popcll(__ballot(MODE == 0 ? active : (active && !walking))); (void)live;
           PT_STAT_ADD(0, 1);                                 // wave-level ray segments
           PT_STAT_ADD(1, live); }                            // live lanes in them
 
-        // ---- the next ray of every live path ----
-        if (active) {
+        // ---- the next ray of every live path (MODE 1: of those whose previous ray has been answered) ----
+        if (active && !walking) {
             const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, P.key0, P.key1);
             f3 d;
             if (fresh) {
@@ -215,6 +242,13 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 dh = normalise(d, len);
                 self_t = self_far_root(h.r, h.n, h.front, dh);
                 active = ok;                                                         // Path Tracer.cpp:100 -> black
+            }
+            if constexpr (MODE == 1) {
+                if (active) {
+                    grid_begin(P.grid, o, dh, 0.001f * len, prev, self_t, gw);
+                    walking = gw.live;
+                    pending = !gw.live;                                              // the big list alone answers this ray
+                }
             }
         }
     }
