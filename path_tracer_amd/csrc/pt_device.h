@@ -130,10 +130,10 @@ PT_DEV f3 sky(float dy) {
 // ---------------------------------------------------------------------------------------------
 PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, int& best_i) {
     asm volatile("" : "+s"(j));   // keep j a scalar register: hipcc otherwise rewrites `j != prev` into a vector add per quad in tier 1
-    float s = fast_sqrt(T);                                       // NaN for T < 0: every compare below is then false
+    float s = fast_sqrt(T);                                       // NaN for T < 0 (Sphere.cpp:13): t1, t2, t are NaN and every compare below is false
     float t1 = b - s, t2 = b + s;
     float t = (t1 >= tmin) ? t1 : t2;                              // Sphere.cpp:17-19
-    bool ok = (T >= 0.0f) & (j != prev) & (t >= tmin) & (t <= best_t);   // :13, :20; <= : later index wins ties
+    bool ok = (j != prev) & (t >= tmin) & (t <= best_t);           // :20; <= : later index wins ties
     best_t = ok ? t : best_t;
     best_i = ok ? j : best_i;
 }
