@@ -87,12 +87,16 @@ def camera_setup(pos=(8, 2, 3), look=(0, 0, 0), up=(0, 1, 0), aspect=16.0 / 9.0,
 def read_settings(text):
     """Parses config text as the reference's main() does. Returns (dict, used_defaults)."""
     lib = load_host_library()
-    out = np.zeros(18)
+    out = np.zeros(26)
     used = lib.pth_read_settings(text.encode(), _p(out))
     s = dict(imageAspectRatio=out[0], imageWidth=int(out[1]), raysPerPixel=int(out[2]), materialMaxDepth=int(out[3]),
              cameraPosition=tuple(out[4:7]), cameraLookingAt=tuple(out[7:10]), cameraUpOrient=tuple(out[10:13]),
              focalLength=out[13], verticalFOV=out[14], apertureSize=out[15], focusDistance=out[16],
-             imageHeight=int(out[17]))
+             imageHeight=int(out[17]),
+             # optional keys of this build (absent: the reference's behaviour)
+             numberOfSpheres=int(out[18]), sceneSeedA=int(out[19]), sceneSeedB=int(out[20]), renderSeed=int(out[21]),
+             sceneHalfExtent=out[22], numberOfGPUs=int(out[23]), outputFormat="P6" if out[24] else "P3",
+             closestHitSearch="grid" if out[25] else "scan")
     return s, bool(used)
 
 

@@ -63,7 +63,9 @@ void pth_camera_setup(const double* pos, const double* look, const double* up, d
 }
 
 // Parses config text as main() does. out[0..16] = aspect, width, spp, depth, pos(3), look(3), up(3), focal, fov,
-// aperture, focus distance; out[17] = height; returns 1 when the all-defaults fallback ran, else 0.
+// aperture, focus distance; out[17] = height; out[18..25] = the optional keys of this build: numberOfSpheres,
+// sceneSeedA, sceneSeedB, renderSeed, sceneHalfExtent, numberOfGPUs, outputFormat == P6, closestHitSearch == grid.
+// Returns 1 when the all-defaults fallback ran, else 0.
 int pth_read_settings(const char* text, double* out) {
     dp::Settings s;
     try {
@@ -77,6 +79,8 @@ int pth_read_settings(const char* text, double* out) {
     out[0] = s.imageAspectRatio; out[1] = s.imageWidth; out[2] = s.raysPerPixel; out[3] = s.materialMaxDepth;
     for (int i = 0; i < 3; ++i) { out[4 + i] = s.cameraPosition[i]; out[7 + i] = s.cameraLookingAt[i]; out[10 + i] = s.cameraUpOrient[i]; }
     out[13] = s.focalLength; out[14] = s.verticalFOV; out[15] = s.apertureSize; out[16] = s.focusDistance; out[17] = s.imageHeight();
+    out[18] = s.numberOfSpheres; out[19] = s.sceneSeedA; out[20] = s.sceneSeedB; out[21] = double(s.renderSeed);
+    out[22] = s.sceneHalfExtent; out[23] = s.numberOfGPUs; out[24] = s.binaryOutput ? 1 : 0; out[25] = s.gridSearch ? 1 : 0;
     return s.usedDefaults ? 1 : 0;
 }
 

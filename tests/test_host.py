@@ -79,6 +79,21 @@ def test_all_or_nothing_fallback():
         assert used_defaults and s["imageWidth"] == 400 and s["raysPerPixel"] == 100
 
 
+def test_optional_keys_default_to_the_reference_behaviour():
+    """Keys this build adds: absent, the program does what the reference does (250 spheres, P3, every sphere tested)."""
+    from path_tracer_amd import host
+    s, used = host.read_settings(REFERENCE_CONFIG)
+    assert not used
+    assert (s["numberOfSpheres"], s["sceneHalfExtent"], s["numberOfGPUs"], s["outputFormat"], s["closestHitSearch"]) == \
+        (250, 10.0, 1, "P3", "scan")
+    s, used = host.read_settings(REFERENCE_CONFIG + "numberOfSpheres = 10000\nsceneHalfExtent = 45\nsceneSeedA = 7\nsceneSeedB = 9\n"
+                                 "renderSeed = 123456789\nnumberOfGPUs = 8\noutputFormat = P6\nclosestHitSearch = grid\n")
+    assert not used
+    assert (s["numberOfSpheres"], s["sceneHalfExtent"], s["sceneSeedA"], s["sceneSeedB"], s["renderSeed"], s["numberOfGPUs"],
+            s["outputFormat"], s["closestHitSearch"]) == (10000, 45.0, 7, 9, 123456789, 8, "P6", "grid")
+    assert s["imageWidth"] == 400 and s["raysPerPixel"] == 100           # the reference's keys are read as before
+
+
 def test_number_of_threads_key_is_ignored():
     s1, _ = host.read_settings(REFERENCE_CONFIG)
     s2, _ = host.read_settings(REFERENCE_CONFIG.replace("numberOfThreads  = 8", "numberOfThreads  = 1"))
