@@ -6,18 +6,23 @@
 // cosine (Dielectric.cpp:19). PhysicsVector<3> becomes three fp32 registers.
 //
 // The closest-hit search (HittableList.cpp:21-36 over Sphere.cpp:5-23) is split in three:
-//   tier 1  every sphere, packed fp32 FMA on sphere PAIRS held in scalar registers:
-//           T = ((c-o).dh)^2 - |c-o|^2 + r^2, written so that the sphere data only multiplies
-//           per-ray constants:  b = c.dh - o.dh,  T = b*b - K + 2 o.c - |o|^2,  K = |c|^2 - r^2
-//           (seven packed FMAs per pair; the per-ray |o|^2 is left to the compare);
-//           T >= 0  <=>  the ray's line meets the sphere (disc >= 0 at Sphere.cpp:10-13);
-//   tier 2  only for the spheres some lane flagged: roots b -+ sqrt(T), the reference's root
-//           choice and range test (Sphere.cpp:16-23), closest-so-far update with ties to the
-//           later index (HittableList.cpp:28-31);
+//   tier 1  every sphere, packed fp32 FMA on sphere PAIRS held in scalar registers. The ray's LINE is
+//           described by dh and a point p of it near the world origin (the foot point
+//           p = o - (o.dh) dh, on the line to an ulp of |p|; its small residual e = p.dh is kept); then
+//           T = r^2 - dist(c, line)^2 = ((c-p).dh)^2 + 2 c.p - |p|^2 - K,   K = |c|^2 - r^2,
+//           in which the sphere data only multiplies per-ray constants: a = c.dh - e, U = a*a - K + 2 c.p
+//           (seven packed FMAs per pair; the per-ray |p|^2 is left to the compare);
+//           T >= 0  <=>  the line meets the sphere (disc >= 0 at Sphere.cpp:10-13). Using p instead of
+//           o keeps the magnitudes at the scale of the scene however far away the ray starts (with o
+//           the discriminant of a small sphere seen from 300 units away drowns in |o|^2 ~ 1e5);
+//   tier 2  only for the spheres some lane flagged: roots a -+ sqrt(T) (distances along the line
+//           measured from p; the ray's own t is that minus o.dh, the same shift for every sphere),
+//           the reference's root choice and range test (Sphere.cpp:16-23), closest-so-far update
+//           with ties to the later index (HittableList.cpp:28-31);
 //   finish  once per ray, for the winning sphere only, in fp64 from the double-precision scene:
 //           t, point, outward normal, front face (Sphere.cpp:26-30, Hittable.h:26-31).
 // The sphere the ray starts on (`prev`) is left out of tier 2 and handled in closed form: its
-// near root is the start point itself, its far root is 2b.
+// near root is the start point itself, its far root is 2 (c-o).dh.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -150,37 +155,39 @@ PT_DEV v16f sload16(const float* p) {
 PT_DEV void swait(v16f& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
 
 // Tier 1 and, when flagged, tier 2 for the four spheres of one record quad R (spheres j .. j+3).
-PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float nod, f3 o2, float oo, int prev, float tmin, float& best_t,
+// dh: unit direction; ne = -p.dh, p2 = 2 p, pp = |p|^2 with p the foot point of the line; tmin and best_t are
+// distances along the line measured from p.
+PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float ne, f3 p2, float pp, int prev, float tmin, float& best_t,
                       int& best_i) {
     // Seven packed FMAs per sphere pair, each with exactly one scalar operand:
-    //   b = c.dh - o.dh;  U = b*b + (-K) + 2 o.c  ( = T + |o|^2 );  the line meets the sphere iff U >= |o|^2.
+    //   a = c.dh - p.dh;  U = a*a + (-K) + 2 p.c  ( = T + |p|^2 );  the line meets the sphere iff U >= |p|^2.
     v2f B[2], U[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const v2f cx = v2f{R[8 * h + 0], R[8 * h + 1]}, cy = v2f{R[8 * h + 2], R[8 * h + 3]};
         const v2f cz = v2f{R[8 * h + 4], R[8 * h + 5]}, nK = v2f{R[8 * h + 6], R[8 * h + 7]};   // nK = r^2 - |c|^2
-        v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{nod, nod});
+        v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{ne, ne});
         b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
         b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
         v2f u = __builtin_elementwise_fma(b, b, nK);
-        u = __builtin_elementwise_fma(cx, v2f{o2.x, o2.x}, u);
-        u = __builtin_elementwise_fma(cy, v2f{o2.y, o2.y}, u);
-        u = __builtin_elementwise_fma(cz, v2f{o2.z, o2.z}, u);
+        u = __builtin_elementwise_fma(cx, v2f{p2.x, p2.x}, u);
+        u = __builtin_elementwise_fma(cy, v2f{p2.y, p2.y}, u);
+        u = __builtin_elementwise_fma(cz, v2f{p2.z, p2.z}, u);
         B[h] = b;
         U[h] = u;
     }
     const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
 #ifdef PT_STATS
     if (threadIdx.x == 0) atomicAdd(&g_stats[2], 1ull);
-    if (__any(m >= oo) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
-    { unsigned long long bm = __ballot(m >= oo); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
+    if (__any(m >= pp) && threadIdx.x == 0) atomicAdd(&g_stats[3], 1ull);
+    { unsigned long long bm = __ballot(m >= pp); if (threadIdx.x == 0) atomicAdd(&g_stats[4], (unsigned long long)__popcll(bm)); }
 #endif
-    if (__any(m >= oo)) {                       // wave-uniform: some lane's line meets a sphere of this quad
+    if (__any(m >= pp)) {                       // wave-uniform: some lane's line meets a sphere of this quad
         // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
-        if (__any(U[0].x >= oo)) tier2(U[0].x - oo, B[0].x, j + 0, prev, tmin, best_t, best_i);
-        if (__any(U[0].y >= oo)) tier2(U[0].y - oo, B[0].y, j + 1, prev, tmin, best_t, best_i);
-        if (__any(U[1].x >= oo)) tier2(U[1].x - oo, B[1].x, j + 2, prev, tmin, best_t, best_i);
-        if (__any(U[1].y >= oo)) tier2(U[1].y - oo, B[1].y, j + 3, prev, tmin, best_t, best_i);
+        if (__any(U[0].x >= pp)) tier2(U[0].x - pp, B[0].x, j + 0, prev, tmin, best_t, best_i);
+        if (__any(U[0].y >= pp)) tier2(U[0].y - pp, B[0].y, j + 1, prev, tmin, best_t, best_i);
+        if (__any(U[1].x >= pp)) tier2(U[1].x - pp, B[1].x, j + 2, prev, tmin, best_t, best_i);
+        if (__any(U[1].y >= pp)) tier2(U[1].y - pp, B[1].y, j + 3, prev, tmin, best_t, best_i);
     }
 }
 
@@ -188,9 +195,16 @@ PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float nod, f3 o2, float oo, i
 // (0.001 * len); prev: sphere the ray starts on, or -1; self_t: the far root of that sphere
 // (self_far_root below). Returns the approximate t and the index of the closest hit (-1: miss).
 PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
-    const float nod = -dot(o, dh);
-    const float oo = dot(o, o);
-    const f3 o2 = o * 2.0f;
+    // The foot point of the line. o.dh carries a rounding error of about an ulp of |o|, which only moves p
+    // ALONG the line; what it leaves behind, p.dh, is small, so it is known accurately and tier 1 subtracts it.
+    const float od = dot(o, dh);
+    const f3 p = fma3(dh, -od, o);
+    const float ne = -dot(p, dh);
+    const f3 p2 = p * 2.0f;
+    const float pp = dot(p, p);
+    const float shift = od;                      // distance from p to o along the line: t = tau - shift
+    tmin += shift;
+    self_t += shift;
     best_t = __builtin_inff();
     best_i = -1;
     // The scan records come through the scalar cache, one s_load_dwordx16 (four spheres) at a time, in two
@@ -205,10 +219,10 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     for (int j = 0; j < n_pad; j += 8) {
         swait(bankA);
         v16f bankB = sload16(rec + 16);
-        scan_quad(bankA, j, dh, nod, o2, oo, prev, tmin, best_t, best_i);
+        scan_quad(bankA, j, dh, ne, p2, pp, prev, tmin, best_t, best_i);
         swait(bankB);
         bankA = sload16(rec + 32);
-        if (j + 4 < n_pad) scan_quad(bankB, j + 4, dh, nod, o2, oo, prev, tmin, best_t, best_i);
+        if (j + 4 < n_pad) scan_quad(bankB, j + 4, dh, ne, p2, pp, prev, tmin, best_t, best_i);
         rec += 32;
     }
     swait(bankA);                                // the last request (never-hit padding) must land before the registers are reused
@@ -219,6 +233,7 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
         best_t = ok ? self_t : best_t;
         best_i = ok ? prev : best_i;
     }
+    best_t -= shift;                             // back to the ray's own (approximate) t; inf stays inf
 }
 
 // Far root of the sphere a scattered ray starts on. The start point p lies on it, so

@@ -144,6 +144,32 @@ def test_scan_T3_live_500_spheres(dev, orc):
     orc.scene_free(hs)
 
 
+def test_scan_rays_from_far_away(dev, orc):
+    """Rays that start hundreds of units out (a bounce off the far ground) and aim at the small spheres: the scan
+    works from the point of the ray's line nearest the world origin, so the distance of the start does not eat
+    the digits of the discriminant. An fp32 direction still places the hit point to ~|o| * 6e-8, which a sphere of
+    radius 0.1 turns into a few 1e-4 of normal; index, t and point keep the 1e-4 bar."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    use(dev, sc, host.camera_setup())
+    hs = orc.scene_create(sc)
+    rng = np.random.default_rng(11)
+    n = 6000
+    far = f32(np.stack([rng.uniform(-300, 300, n), rng.uniform(0.01, 40, n), rng.uniform(-300, 300, n)], axis=1))
+    aim = f32(np.stack([rng.uniform(-10, 10, n), rng.uniform(0, 0.5, n), rng.uniform(-10, 10, n)], axis=1))
+    d = f32(aim - far)
+    out, ref = dev.scan(far, d), orc.scan(hs, far, d)
+    orc.scene_free(hs)
+    mism = out["idx"] != ref["idx"]
+    assert mism.sum() <= 8, mism.sum()
+    hit = ~mism & (ref["idx"] >= 0)
+    assert hit.sum() > 0.5 * n and (ref["idx"][hit] > 4).sum() > 0.2 * n        # plenty of small spheres among the hits
+    assert (np.abs(out["t"][hit] - ref["t"][hit]) / ref["t"][hit]).max() < REL
+    assert vec_rel_err(out["p"][hit], ref["p"][hit]).max() < REL
+    assert np.abs(out["n"][hit] - ref["n"][hit]).max() < 2e-3
+    assert np.array_equal(out["front"][hit], ref["front"][hit])
+
+
 def test_scan_kats_and_edges(dev, orc, kat):
     for name in ("sphere_hit", "sphere_hit_inside"):
         k = kat[name]
