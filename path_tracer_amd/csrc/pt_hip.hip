@@ -224,7 +224,12 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 
         // ---- the next ray of every live path (MODE 1: of those whose previous ray has been answered) ----
         if (active && !walking) {
-            const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, P.key0, P.key1);
+            // The ten round keys are wave-uniform. Left alone, hipcc computes them once, runs out of scalar registers
+            // and parks them in vector lanes (20 v_readlane per iteration); opaque copies of the key make it
+            // rebuild them here with scalar adds, which cost the vector ALU nothing.
+            uint32_t key0 = P.key0, key1 = P.key1;
+            asm volatile("" : "+s"(key0), "+s"(key1));
+            const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, key0, key1);
             f3 d;
             if (fresh) {
                 // jitter, then a polar map of two uniforms onto the unit disk (same distribution as
