@@ -153,3 +153,17 @@ def test_grid_edges(gdev, orc, dev):
     assert ra == rb and np.array_equal(a, b)
     c, rc = gdev.render_image(96, 54, 3, 50, seed=5)
     assert abs(rc - rb) < 0.005 * rb and (np.abs(c - b).max(axis=2) / 3 > 2e-3).mean() < 0.02
+    # the corners of the sample loop in grid mode: depth 0 and 1, an empty sample range, partial tiles, sample ranges that add up
+    img, rays = gdev.render_image(40, 23, 3, 0)
+    assert rays == 0 and not img.any()
+    img, rays = gdev.render_image(40, 23, 2, 1)
+    assert rays == 40 * 23 * 2
+    gdev.clear_accum(40, 23)
+    assert gdev.render(40, 23, 5, 5, 50, 1, want_rays=True) == 0 and not gdev.read_accum(40, 23).any()
+    a, ra = gdev.render_image(101, 57, 6, 50, seed=9)
+    b, rb = dev.render_image(101, 57, 6, 50, seed=9)
+    assert abs(ra - rb) < 0.005 * rb and (np.abs(a - b).max(axis=2) / 6 > 2e-3).mean() < 0.02
+    gdev.clear_accum(101, 57)
+    r1 = gdev.render(101, 57, 0, 2, 50, 9, want_rays=True)
+    r2 = gdev.render(101, 57, 2, 6, 50, 9, want_rays=True)
+    assert r1 + r2 == ra and np.abs(gdev.read_accum(101, 57) - a).max() <= 4e-6 * max(1.0, float(a.max()))
