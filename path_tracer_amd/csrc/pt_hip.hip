@@ -89,7 +89,7 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #define PT_WAVES_PER_EU 6
 #endif
 #ifndef PT_GRID_WAVES_PER_EU
-#define PT_GRID_WAVES_PER_EU 6      // 80 registers: at 8 waves (64) the walk state spills and the kernel runs at half the speed
+#define PT_GRID_WAVES_PER_EU 5      // 96 registers, no spills; at 8 waves (64) the walk state spills and the kernel runs at half the speed
 #endif
 #ifndef PT_GRID_RATIO
 #define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
