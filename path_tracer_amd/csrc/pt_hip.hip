@@ -84,7 +84,8 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 // Persistent waves. Each wave pulls jobs (8x8 tile x sample chunk) from a global counter and hands
 // the job's (sample, pixel-slot) items to its lanes as their paths end. When a job's items run out
 // the wave moves straight on to the next job while the last paths of the previous one are still in
-// flight (two LDS banks of sums, flushed when drained), so lanes idle only at the very end of the frame.
+// flight (two LDS banks of sums; the older one is flushed at the switch and its stragglers then add to the
+// frame directly), so lanes idle only at the very end of the frame.
 #ifndef PT_WAVES_PER_EU
 #define PT_WAVES_PER_EU 6
 #endif
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     float len = 1.0f;
     float self_t = 0.0f;
     int slot = 0, bounce = 0, prev = -1, lbank = 0;
-    uint32_t pixel = 0, sample = 0;
+    uint32_t pixel = 0, sample = 0, top_pixel = 0;   // pixel: counted from the bottom row like the reference's j; top_pixel: index into the frame
 
     // MODE 1 only: the walk through the grid of this lane's ray, and whether its answer waits to be used
     GridWalk gw;
@@ -155,10 +156,20 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             else { grid_end(gw, prev, self_t, bt, bi); pending = false; }
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
-                unsigned long long* a = acc + 192 * lbank + slot * 3;
-                atomicAdd(a + 0, to_fx(c.x));
-                atomicAdd(a + 1, to_fx(c.y));
-                atomicAdd(a + 2, to_fx(c.z));
+                if (lbank < 2) {
+                    unsigned long long* a = acc + 192 * lbank + slot * 3;
+                    atomicAdd(a + 0, to_fx(c.x));
+                    atomicAdd(a + 1, to_fx(c.y));
+                    atomicAdd(a + 2, to_fx(c.z));
+                } else {
+                    // a straggler whose job's sums have gone to the frame already (see the job switch below)
+                    const size_t plane = size_t(P.W) * size_t(P.H);
+                    unsigned long long* dst = P.accum_fx + top_pixel;
+                    const unsigned long long vx = to_fx(c.x), vy = to_fx(c.y), vz = to_fx(c.z);
+                    if (vx) atomicAdd(dst, vx);
+                    if (vy) atomicAdd(dst + plane, vy);
+                    if (vz) atomicAdd(dst + 2 * plane, vz);
+                }
                 active = false;
             } else {
                 h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
@@ -177,7 +188,10 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
         while (__any(need)) {
             if (c_next >= c_total) {                         // wave-uniform: the current job is handed out
                 if (no_more_jobs) break;
-                if (__any(active && lbank != parity)) break; // the other bank is still draining: wait for it
+                // The other bank may still have paths in flight (a path of 30 bounces outlives the whole next job).
+                // Waiting for them would idle every finished lane; instead its sums go to the frame now and the
+                // stragglers add their result straight to the frame when they end (integer sums: any order).
+                if (active && lbank != parity) lbank = 2;
                 if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
                 int job = 0;
                 if (lane == 0) job = int(atomicAdd(P.job_counter, 1u));
@@ -209,6 +223,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                     bounce = 0;
                     prev = -1;
                     lbank = parity;
+                    top_pixel = uint32_t(py) * uint32_t(P.W) + uint32_t(px);
                     fresh = active = true;
                     need = false;
                 }
