@@ -409,6 +409,30 @@ def test_full_size_properties(dev, orc):
     assert rays2 == rays and np.array_equal(img, img2)
 
 
+def test_4k_frame_split_across_sample_ranges(dev):
+    """configs[2] at full width and height (3840x2160; 32 spp instead of 1024, the properties do not depend on it):
+    the frame rendered as 8 disjoint sample ranges (what 8 GPUs do) and summed equals the frame rendered in one
+    call up to float addition order, ray counts add up exactly, and the image statistics are those of the scene."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    use(dev, sc, host.camera_setup())
+    W, H, spp = 3840, 2160, 32
+    whole, rays = dev.render_image(W, H, spp, 50, seed=42)
+    assert np.isfinite(whole).all() and whole.min() >= 0 and whole.max() <= spp * 1.0001
+    assert 2.3 < rays / (W * H * spp) < 3.0
+    parts = np.zeros_like(whole, dtype=np.float64)
+    total = 0
+    for g in range(8):
+        img, r = dev.render_image(W, H, spp // 8, 50, seed=42, spp_begin=g * (spp // 8))
+        parts += img
+        total += r
+    assert total == rays
+    assert np.abs(parts - whole).max() <= 1e-5 * spp
+    # a 1080p frame of the same scene and seed has the same mean luminance (different pixel grid, same integrand)
+    small, _ = dev.render_image(1920, 1080, spp, 50, seed=42)
+    assert abs(float(whole.mean()) - float(small.mean())) < 0.003 * float(small.mean())
+
+
 def test_large_scene_10k_spheres(dev, orc):
     """configs[4]: 10,000 random spheres on a half extent of 45; scan and a small frame."""
     from path_tracer_amd import host
