@@ -233,7 +233,10 @@ def main():
             except Exception as e:                                   # never lose the headline line to an extra
                 out["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.spheres, min(16, os.cpu_count() or 1))
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.spheres, min(16, os.cpu_count() or 1))
+            except Exception as e:                                   # e.g. oracle/_build missing: the headline line still prints
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
