@@ -41,13 +41,25 @@ struct RenderParams {
     int max_depth;
     uint32_t key0, key1;
     float inv_w1, inv_h1;
-    CameraDev cam;
+    const float* cam_dev;            // the 19 floats of a CameraDev in device memory (read with scalar loads where used)
     SceneDev scene;
     GridDev grid;                    // read by k_render<1> only
     unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
     unsigned long long* ray_count;   // rays of this call
     unsigned int* job_counter;       // next job to hand out, zero at launch
 };
+
+// A CameraDev from its 19 floats in device memory; the constant address space makes hipcc use scalar loads
+// although the kernel also contains atomics.
+typedef const float __attribute__((address_space(4)))* const_float_ptr;
+PT_DEV CameraDev load_camera(const float* p) {
+    const_float_ptr f = (const_float_ptr)(uintptr_t)p;
+    CameraDev c;
+    c.pos = mk3(f[0], f[1], f[2]); c.ll_rel = mk3(f[3], f[4], f[5]); c.hor = mk3(f[6], f[7], f[8]);
+    c.ver = mk3(f[9], f[10], f[11]); c.u = mk3(f[12], f[13], f[14]); c.v = mk3(f[15], f[16], f[17]);
+    c.lens = f[18];
+    return c;
+}
 
 // Radiance in [0, 1] per channel (every attenuation and the sky are <= 1) to unsigned Q32.32.
 // Integer sums make the frame independent of the order in which lanes and jobs finish.
@@ -250,7 +262,14 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 // jitter, then a polar map of two uniforms onto the unit disk (same distribution as
                 // the rejection loop of VectorFunc.cpp:57-64)
                 const float rad = fast_sqrt(u24(r.z)), ang = u24(r.w);
-                gen_ray(P.cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang), rad * sin_rev(ang), o, d);
+                // The camera is read here, through the scalar cache, rather than carried in scalar registers for the
+                // whole kernel: the scan needs those registers, and hipcc would park the camera in vector lanes and
+                // fetch it back value by value with vector instructions. The opaque copy of the pointer keeps the
+                // loads inside this block.
+                const float* cam_ptr = P.cam_dev;
+                asm volatile("" : "+s"(cam_ptr));
+                const CameraDev cam = load_camera(cam_ptr);
+                gen_ray(cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang), rad * sin_rev(ang), o, d);
                 thr = mk3(1, 1, 1);
                 dh = normalise(d, len);
             }
@@ -414,6 +433,7 @@ struct pt_context {
     double grid_big_ratio = 3.0;               // radius above ratio x median: big list (PT_GRID_BIG_RATIO)
     int resident_waves_grid = 0;
     CameraDev cam;
+    float* d_cam = nullptr;                     // device copy of `cam` (19 floats), read by k_render
     // frame
     unsigned long long* d_fx = nullptr;
     size_t fx_elems = 0;
@@ -635,7 +655,7 @@ int pt_destroy(pt_handle h) {
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
-    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters);
+    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam);
     (void)hipFree(h->d_cell_start); (void)hipFree(h->d_items); (void)hipFree(h->d_item_ids);
     (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan);
     (void)hipStreamDestroy(h->own_stream);
@@ -729,6 +749,11 @@ int pt_set_camera(pt_handle h, const double position[3], const double lower_left
     h->cam.ll_rel = f(rel);
     h->cam.hor = f(horizontal); h->cam.ver = f(vertical); h->cam.u = f(u); h->cam.v = f(v);
     h->cam.lens = float(lens_radius);
+    static_assert(sizeof(CameraDev) == 19 * sizeof(float), "CameraDev is 19 packed floats");
+    PT_HIP(h, hipSetDevice(h->device));
+    PT_HIP(h, hipStreamSynchronize(h->stream));          // a render in flight may still read the old camera
+    if (!h->d_cam) PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_cam), 32 * sizeof(float)));
+    PT_HIP(h, hipMemcpy(h->d_cam, &h->cam, sizeof(CameraDev), hipMemcpyHostToDevice));
     h->have_camera = true;
     return 0;
 }
@@ -835,7 +860,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         // (W - 1) and (H - 1) divide by zero for a one-pixel-wide image in the reference too
         // (Path Tracer.cpp:270-271); the float reciprocal is inf there as well.
         P.inv_w1 = 1.0f / float(width - 1); P.inv_h1 = 1.0f / float(height - 1);
-        P.cam = h->cam;
+        P.cam_dev = h->d_cam;
         P.scene = scene_dev(h);
         const bool use_grid = h->accel == PT_ACCEL_GRID;
         if (use_grid && !h->grid_ready) return fail(h, PT_ERR_STATE, "pt_render: the grid has not been built");
