@@ -26,10 +26,16 @@ struct GridDev {
     const int* big_ids;           // list index of each sphere of the big list
     const int* big_local;         // per list index: position in the big list, or -1
     SceneDev big;                 // scan records of the big list (geom / mat unused)
-    f3 gmin, gmax;                // box the cells tile
+    int last_cell;                // nx * ny * nz - 1
+    const float* shape;           // device copy of a GridShape: read with scalar loads where a walk is set up
+};
+struct GridShape {                // 11 dwords
+    float gmin[3], gmax[3];       // box the cells tile
     float cell, inv_cell;         // cell edge
     int nx, ny, nz;
 };
+typedef const float __attribute__((address_space(4)))* grid_const_float_ptr;
+typedef const int __attribute__((address_space(4)))* grid_const_int_ptr;
 
 PT_DEV float nonzero(float d) { return __builtin_fabsf(d) < 1e-12f ? __builtin_copysignf(1e-12f, d) : d; }
 
@@ -58,10 +64,20 @@ PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, floa
     w.best_t = best_t; w.best_i = best_i; w.tmin = tmin;
     w.prev_in_grid = (prev >= 0) & (prev_local < 0);
 
+    // The shape of the grid comes through the scalar cache here, where it is used (an opaque copy of the pointer
+    // keeps hipcc from hoisting the loads and parking eleven more values in vector lanes for the whole kernel).
+    const float* shape = G.shape;
+    asm volatile("" : "+s"(shape));
+    grid_const_float_ptr gf = (grid_const_float_ptr)(uintptr_t)shape;
+    grid_const_int_ptr gi = (grid_const_int_ptr)(uintptr_t)shape;
+    const f3 gmin = mk3(gf[0], gf[1], gf[2]), gmax = mk3(gf[3], gf[4], gf[5]);
+    const float cell = gf[6], inv_cell = gf[7];
+    const int nx = gi[8], ny = gi[9], nz = gi[10];
+
     // ---- clip the ray to the box of the grid ----
     const f3 dn = mk3(nonzero(dh.x), nonzero(dh.y), nonzero(dh.z));   // the walk only: a zero component would make 0 * inf
     const f3 inv = mk3(fast_rcp(dn.x), fast_rcp(dn.y), fast_rcp(dn.z));
-    const f3 ta = (G.gmin - o) * inv, tb = (G.gmax - o) * inv;
+    const f3 ta = (gmin - o) * inv, tb = (gmax - o) * inv;
     const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ta.x, tb.x), __builtin_fminf(ta.y, tb.y)),
                                        __builtin_fmaxf(__builtin_fminf(ta.z, tb.z), 0.0f));
     w.t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ta.x, tb.x), __builtin_fmaxf(ta.y, tb.y)),
@@ -69,17 +85,17 @@ PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, floa
     w.live = (t_in <= w.t_out) & (t_in <= best_t);
 
     // ---- the cell the ray enters at, the distance to the next cell wall on each axis ----
-    const f3 q = (fma3(dh, t_in, o) - G.gmin) * G.inv_cell;
-    const int ix = min(max(int(__builtin_floorf(q.x)), 0), G.nx - 1);
-    const int iy = min(max(int(__builtin_floorf(q.y)), 0), G.ny - 1);
-    const int iz = min(max(int(__builtin_floorf(q.z)), 0), G.nz - 1);
+    const f3 q = (fma3(dh, t_in, o) - gmin) * inv_cell;
+    const int ix = min(max(int(__builtin_floorf(q.x)), 0), nx - 1);
+    const int iy = min(max(int(__builtin_floorf(q.y)), 0), ny - 1);
+    const int iz = min(max(int(__builtin_floorf(q.z)), 0), nz - 1);
     const bool fx = dn.x > 0.0f, fy = dn.y > 0.0f, fz = dn.z > 0.0f;
-    w.tmx = (__builtin_fmaf(float(ix + (fx ? 1 : 0)), G.cell, G.gmin.x) - o.x) * inv.x;
-    w.tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), G.cell, G.gmin.y) - o.y) * inv.y;
-    w.tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), G.cell, G.gmin.z) - o.z) * inv.z;
-    w.tdx = G.cell * __builtin_fabsf(inv.x); w.tdy = G.cell * __builtin_fabsf(inv.y); w.tdz = G.cell * __builtin_fabsf(inv.z);
-    w.sx = fx ? 1 : -1; w.sy = fy ? G.nx : -G.nx; w.sz = fz ? G.nx * G.ny : -(G.nx * G.ny);
-    w.ci = (iz * G.ny + iy) * G.nx + ix;
+    w.tmx = (__builtin_fmaf(float(ix + (fx ? 1 : 0)), cell, gmin.x) - o.x) * inv.x;
+    w.tmy = (__builtin_fmaf(float(iy + (fy ? 1 : 0)), cell, gmin.y) - o.y) * inv.y;
+    w.tmz = (__builtin_fmaf(float(iz + (fz ? 1 : 0)), cell, gmin.z) - o.z) * inv.z;
+    w.tdx = cell * __builtin_fabsf(inv.x); w.tdy = cell * __builtin_fabsf(inv.y); w.tdz = cell * __builtin_fabsf(inv.z);
+    w.sx = fx ? 1 : -1; w.sy = fy ? nx : -nx; w.sz = fz ? nx * ny : -(nx * ny);
+    w.ci = (iz * ny + iy) * nx + ix;
     w.k = 0; w.kend = 0;
     if (w.live) { w.k = G.cell_start[w.ci]; w.kend = G.cell_start[w.ci + 1]; }
 }
@@ -105,7 +121,7 @@ PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
     w.tmy += my ? w.tdy : 0.0f;
     w.tmz += mz ? w.tdz : 0.0f;
     int ci = w.ci + (mx ? w.sx : (my ? w.sy : (mz ? w.sz : 0)));
-    ci = min(max(ci, 0), G.nx * G.ny * G.nz - 1);
+    ci = min(max(ci, 0), G.last_cell);
     w.ci = ci;
     const uint32_t r0 = G.cell_start[ci], r1 = G.cell_start[ci + 1];
     // -- the test, for the lanes with an entry: Sphere.cpp:6-19 relative to the ray origin --

@@ -427,7 +427,9 @@ struct pt_context {
     int* d_big_ids = nullptr;
     int* d_big_local = nullptr;
     float* d_big_scan = nullptr;
+    float* d_grid_shape = nullptr;
     GridDev grid;
+    double grid_cell = 0;
     int grid_info[6] = {0, 0, 0, 0, 0, 0};     // nx, ny, nz, spheres in the big list, entries, fullest cell
     double grid_cell_scale = 4.0;              // cell edge = scale x median radius (PT_GRID_CELL_SCALE)
     double grid_big_ratio = 3.0;               // radius above ratio x median: big list (PT_GRID_BIG_RATIO)
@@ -604,10 +606,17 @@ static int build_grid(pt_handle h) {
     g.cell_start = h->d_cell_start; g.items = h->d_items; g.ids = h->d_item_ids;
     g.big_ids = h->d_big_ids; g.big_local = h->d_big_local;
     g.big.scan = h->d_big_scan; g.big.geom = nullptr; g.big.mat = nullptr; g.big.n = int(big.size()); g.big.n_pad = big_pad;
-    g.gmin = f3{gmin[0], gmin[1], gmin[2]};
-    g.gmax = f3{gmin[0] + fcell * float(dims[0]), gmin[1] + fcell * float(dims[1]), gmin[2] + fcell * float(dims[2])};
-    g.cell = fcell; g.inv_cell = 1.0f / fcell;
-    g.nx = dims[0]; g.ny = dims[1]; g.nz = dims[2];
+    GridShape shape;
+    for (int a = 0; a < 3; ++a) { shape.gmin[a] = gmin[a]; shape.gmax[a] = gmin[a] + fcell * float(dims[a]); }
+    shape.cell = fcell; shape.inv_cell = 1.0f / fcell;
+    shape.nx = dims[0]; shape.ny = dims[1]; shape.nz = dims[2];
+    static_assert(sizeof(GridShape) == 11 * sizeof(float), "GridShape is 11 dwords");
+    std::vector<float> shape_words(16, 0.0f);
+    std::memcpy(shape_words.data(), &shape, sizeof(shape));
+    if ((rc = upload(h, &h->d_grid_shape, shape_words))) return rc;
+    g.shape = h->d_grid_shape;
+    g.last_cell = int(n_cells) - 1;
+    h->grid_cell = double(fcell);
     h->grid_info[0] = dims[0]; h->grid_info[1] = dims[1]; h->grid_info[2] = dims[2];
     h->grid_info[3] = int(big.size()); h->grid_info[4] = n_entries; h->grid_info[5] = fullest;
     h->grid_ready = true;
@@ -657,7 +666,7 @@ int pt_destroy(pt_handle h) {
     (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
     (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam);
     (void)hipFree(h->d_cell_start); (void)hipFree(h->d_items); (void)hipFree(h->d_item_ids);
-    (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan);
+    (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan); (void)hipFree(h->d_grid_shape);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -735,7 +744,7 @@ int pt_accel_info(pt_handle h, int info[6], double* cell_edge) {
     if (!h || !info) return PT_ERR_INVALID;
     if (!h->grid_ready) return fail(h, PT_ERR_STATE, "pt_accel_info: no grid has been built (pt_set_accel(PT_ACCEL_GRID) and pt_set_scene first)");
     for (int i = 0; i < 6; ++i) info[i] = h->grid_info[i];
-    if (cell_edge) *cell_edge = double(h->grid.cell);
+    if (cell_edge) *cell_edge = h->grid_cell;
     return 0;
 }
 
