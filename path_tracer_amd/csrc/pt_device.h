@@ -248,6 +248,18 @@ PT_DEV float self_far_root(float r, f3 n, bool front, f3 dh_new) {
 // Finish: the hit record of the winning sphere in fp64 (Sphere.cpp:6-30, Hittable.h:26-31).
 // t and tmin are in unit-direction units; the reference's t is t / len.
 // ---------------------------------------------------------------------------------------------
+// sqrt(x) for x >= 0 to ~1e-14 relative: the fp32 reciprocal square root as a seed, one Newton step in fp64
+// (s = x r is off by d ~ 1e-7; s + r (x - s^2) / 2 is off by 1.5 d^2). A third of the instructions of the
+// correctly rounded fp64 square root hipcc expands to; the finish needs 1e-9 at most.
+PT_DEV double sqrt_refined(double x) {
+    const float xf = float(x);
+    const double r = double(__builtin_amdgcn_rsqf(xf));
+    const double s = x * r;
+    const double e = __builtin_fma(-s, s, x);
+    const double s1 = __builtin_fma(0.5 * r, e, s);
+    return xf > 1e-30f ? s1 : 0.0;               // a tangent hit: 0 (and no inf * 0)
+}
+
 struct HitRec {
     f3 p, n;
     bool front;
@@ -264,7 +276,7 @@ PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, do
     const double cc = ocx * ocx + ocy * ocy + ocz * ocz - g.r2;                  // :9
     double disc = hb * hb - a * cc;                                              // :10
     disc = disc < 0.0 ? 0.0 : disc;      // tier 2 said "hit" in fp32; a grazing miss becomes a tangent hit
-    const double sq = __builtin_sqrt(disc);                                      // :16
+    const double sq = sqrt_refined(disc);                                        // :16
     const double inv_a = 2.0 - a;        // 1/a to 4e-14 since |a - 1| <= 2e-7
     const double t1 = (-hb - sq) * inv_a;                                        // :17
     const double t2 = (-hb + sq) * inv_a;                                        // :19
