@@ -167,3 +167,42 @@ def test_grid_edges(gdev, orc, dev):
     r1 = gdev.render(101, 57, 0, 2, 50, 9, want_rays=True)
     r2 = gdev.render(101, 57, 2, 6, 50, 9, want_rays=True)
     assert r1 + r2 == ra and np.abs(gdev.read_accum(101, 57) - a).max() <= 4e-6 * max(1.0, float(a.max()))
+
+
+def test_random_scenes_both_searches(gdev, dev, orc):
+    """Seeded random scenes the generator never makes: radii over three decades, spheres that overlap and contain
+    one another (so rays start INSIDE spheres and the far root of Sphere.cpp:19 decides), flat, cubic and
+    clustered layouts. Both searches against the oracle's HittableList::isHit."""
+    rng = np.random.default_rng(2026)
+    for case in range(8):
+        n = int(rng.integers(3, 900))
+        layout = case % 4
+        if layout == 0:      # cube
+            c = rng.uniform(-8, 8, size=(n, 3))
+        elif layout == 1:    # slab
+            c = np.stack([rng.uniform(-30, 30, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-30, 30, n)], axis=1)
+        elif layout == 2:    # clusters
+            centres = rng.uniform(-20, 20, size=(5, 3))
+            c = centres[rng.integers(0, 5, n)] + rng.normal(scale=1.0, size=(n, 3))
+        else:                # a line of spheres plus a few enclosing ones
+            c = np.stack([np.linspace(-15, 15, n), np.zeros(n), np.zeros(n)], axis=1) + rng.normal(scale=0.05, size=(n, 3))
+        r = 10.0 ** rng.uniform(-2.0, 0.7, n)
+        r[rng.integers(0, n, 2)] = rng.uniform(10, 60, 2)          # spheres that contain much of the scene
+        lst = [{"c": list(map(float, c[i])), "r": float(r[i])} for i in range(n)]
+        sc = spheres(lst)
+        m = 4096
+        o = f32(c[rng.integers(0, n, m)] + rng.normal(scale=2.0, size=(m, 3)))
+        d = f32(rng.normal(size=(m, 3)) * rng.uniform(0.1, 5, size=(m, 1)))
+        hs = orc.scene_create(sc)
+        ref = orc.scan(hs, o, d)
+        orc.scene_free(hs)
+        assert (ref["idx"] >= 0).mean() > 0.5
+        for device in (gdev, dev):
+            device.set_scene(sc)
+            out = device.scan(o, d)
+            mism = out["idx"] != ref["idx"]
+            assert mism.sum() <= 6, (case, n, int(mism.sum()))
+            hit = ~mism & (ref["idx"] >= 0)
+            assert (np.abs(out["t"][hit] - ref["t"][hit]) / ref["t"][hit]).max() < 1e-4
+            assert np.array_equal(out["front"][hit], ref["front"][hit])
+            assert (ref["front"][hit] == 0).sum() > 0              # rays that start inside a sphere are among them
