@@ -107,20 +107,37 @@ PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, floa
 // the box (should rounding let it take one more step, the cell index is clamped to the table: a cell too many
 // is looked at, which cannot change the answer, and the next exit distance lies beyond the box for certain).
 // Every pass consumes an entry or moves one cell on: at most nx + ny + nz + 3 + entries passes per walk.
+// FLAT: the grid is one layer of cells (ny = 1, the reference's scenes: spheres on the ground). The walk then
+// never moves along y; where the ray leaves the layer is the far side of the box, t_out.
+template <bool FLAT>
 PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
     const bool has = w.k < w.kend;
     const float4 s = G.items[w.k];                    // one entry past the last is allocated: k == kend is readable
     const int id = G.ids[w.k];
     // -- the step, for the lanes whose cell is used up --
-    const float t_exit = __builtin_fminf(__builtin_fminf(w.tmx, w.tmy), w.tmz);
-    const bool stop = !has & ((w.best_t < t_exit) | (t_exit >= w.t_out));
-    const bool st = !has & !stop;
-    const bool ax = (w.tmx <= w.tmy) & (w.tmx <= w.tmz), ay = !ax & (w.tmy <= w.tmz);
-    const bool mx = st & ax, my = st & ay, mz = st & !ax & !ay;
-    w.tmx += mx ? w.tdx : 0.0f;
-    w.tmy += my ? w.tdy : 0.0f;
-    w.tmz += mz ? w.tdz : 0.0f;
-    int ci = w.ci + (mx ? w.sx : (my ? w.sy : (mz ? w.sz : 0)));
+    float t_exit;
+    bool stop;
+    int ci;
+    if constexpr (FLAT) {
+        t_exit = __builtin_fminf(w.tmx, w.tmz);
+        stop = !has & ((w.best_t < t_exit) | (t_exit >= w.t_out));
+        const bool st = !has & !stop;
+        const bool ax = w.tmx <= w.tmz;
+        const bool mx = st & ax, mz = st & !ax;
+        w.tmx += mx ? w.tdx : 0.0f;
+        w.tmz += mz ? w.tdz : 0.0f;
+        ci = w.ci + (mx ? w.sx : (mz ? w.sz : 0));
+    } else {
+        t_exit = __builtin_fminf(__builtin_fminf(w.tmx, w.tmy), w.tmz);
+        stop = !has & ((w.best_t < t_exit) | (t_exit >= w.t_out));
+        const bool st = !has & !stop;
+        const bool ax = (w.tmx <= w.tmy) & (w.tmx <= w.tmz), ay = !ax & (w.tmy <= w.tmz);
+        const bool mx = st & ax, my = st & ay, mz = st & !ax & !ay;
+        w.tmx += mx ? w.tdx : 0.0f;
+        w.tmy += my ? w.tdy : 0.0f;
+        w.tmz += mz ? w.tdz : 0.0f;
+        ci = w.ci + (mx ? w.sx : (my ? w.sy : (mz ? w.sz : 0)));
+    }
     ci = min(max(ci, 0), G.last_cell);
     w.ci = ci;
     const uint32_t r0 = G.cell_start[ci], r1 = G.cell_start[ci + 1];
@@ -153,6 +170,7 @@ PT_DEV void grid_end(const GridWalk& w, int prev, float self_t, float& best_t, i
 
 // Same contract as scan_spheres (pt_device.h): best_i is a LIST index. The whole search for one ray per lane;
 // the wave stays in the loop until its last lane is done (the sample loop interleaves walks instead).
+template <bool FLAT>
 PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
     GridWalk w;
     grid_begin(G, o, dh, tmin, prev, self_t, w);
@@ -163,7 +181,7 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
             if (threadIdx.x == 0) { atomicAdd(&g_stats[5], 1ull); atomicAdd(&g_stats[6], (unsigned long long)__popcll(lm)); atomicAdd(&g_stats[7], (unsigned long long)__popcll(hm)); }
         }
 #endif
-        if (w.live) grid_pass(G, o, dh, prev, w);
+        if (w.live) grid_pass<FLAT>(G, o, dh, prev, w);
     }
     grid_end(w, prev, self_t, best_t, best_i);
 }

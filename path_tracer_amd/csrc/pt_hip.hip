@@ -1,7 +1,7 @@
 // pt_hip.hip — kernels and C-ABI of libpt_hip.so (gfx950 only; see include/pt_hip.h).
 //
 // Kernels
-//   k_render<MODE>  the sample loop (MODE 0: linear scan of every sphere, the default; MODE 1: the same
+//   k_render<MODE>  the sample loop (MODE 0: linear scan of every sphere, the default; MODE 1 and 2: the same
 //              loop with the closest-hit search through the uniform grid of pt_grid.h): per-lane iterative bounce loop with path regeneration, persistent
 //              waves. A wave (one 64-thread workgroup) pulls jobs = an 8x8 pixel tile x a chunk of
 //              samples from a global counter and hands (pixel, sample) items to its lanes as their
@@ -43,7 +43,7 @@ struct RenderParams {
     float inv_w1, inv_h1;
     const float* cam_dev;            // the 19 floats of a CameraDev in device memory (read with scalar loads where used)
     SceneDev scene;
-    GridDev grid;                    // read by k_render<1> only
+    GridDev grid;                    // read by k_render<1> and k_render<2> only
     unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
     unsigned long long* ray_count;   // rays of this call
     unsigned int* job_counter;       // next job to hand out, zero at launch
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     int slot = 0, bounce = 0, prev = -1, lbank = 0;
     uint32_t pixel = 0, sample = 0, top_pixel = 0;   // pixel: counted from the bottom row like the reference's j; top_pixel: index into the frame
 
-    // MODE 1 only: the walk through the grid of this lane's ray, and whether its answer waits to be used
+    // MODE 1 (grid of several layers) and 2 (one layer of cells) only: the walk through the grid of this lane's ray, and whether its answer waits to be used
     GridWalk gw;
     gw.tmx = gw.tmy = gw.tmz = gw.tdx = gw.tdy = gw.tdz = gw.t_out = gw.tmin = gw.best_t = 0.0f;
     gw.best_i = -1; gw.ci = gw.sx = gw.sy = gw.sz = 0; gw.k = gw.kend = 0u; gw.prev_in_grid = false; gw.live = false;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
         HitRec h;
         MatRec mat;
         bool hit = false;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE != 0) {
             // Walks differ in length from lane to lane. Rather than wait for the longest, the wave walks until
             // at most a quarter of its rays are still on their way, handles the answers of the others (below),
             // gives those lanes their next rays and comes back here; the walks still in progress simply go on.
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                   PT_STAT_ADD(5, 1); PT_STAT_ADD(6, nw); PT_STAT_ADD(7, nh); }
 #endif
                 if (walking) {
-                    grid_pass(P.grid, o, dh, prev, gw);
+                    grid_pass<MODE == 2>(P.grid, o, dh, prev, gw);
                     if (!gw.live) { walking = false; pending = true; }
                 }
             }
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 self_t = self_far_root(h.r, h.n, h.front, dh);
                 active = ok;                                                         // Path Tracer.cpp:100 -> black
             }
-            if constexpr (MODE == 1) {
+            if constexpr (MODE != 0) {
                 if (active) {
                     grid_begin(P.grid, o, dh, 0.001f * len, prev, self_t, gw);
                     walking = gw.live;
@@ -338,7 +338,7 @@ __global__ void k_scan(SceneDev sc, GridDev grid, int n, const double* o, const 
     const f3 dh = normalise(rd, len);
     float bt; int bi;
     if constexpr (MODE == 0) scan_spheres(sc, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
-    else scan_grid(grid, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
+    else scan_grid<MODE == 2>(grid, ro, dh, float(t_min) * len, -1, 0.0f, bt, bi);
     idx[k] = bi;
     if (bi < 0) {
         t[k] = 0; front[k] = 0;
@@ -434,6 +434,7 @@ struct pt_context {
     double grid_cell_scale = 4.0;              // cell edge = scale x median radius (PT_GRID_CELL_SCALE)
     double grid_big_ratio = 3.0;               // radius above ratio x median: big list (PT_GRID_BIG_RATIO)
     int resident_waves_grid = 0;
+    bool grid_flat_ok = true;                  // PT_GRID_FLAT=0: always the general walk (diagnostic)
     CameraDev cam;
     float* d_cam = nullptr;                     // device copy of `cam` (19 floats), read by k_render
     // frame
@@ -653,6 +654,7 @@ int pt_create(int device_index, pt_handle* out) {
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
     if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
+    if (const char* gf = std::getenv("PT_GRID_FLAT")) h->grid_flat_ok = std::atoi(gf) != 0;
     if (const char* br = std::getenv("PT_GRID_BIG_RATIO")) { double v = std::atof(br); if (v >= 1 && v < 1e6) h->grid_big_ratio = v; }
     *out = h;
     return 0;
@@ -878,10 +880,11 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         P.ray_count = h->d_counters;
         P.job_counter = reinterpret_cast<unsigned int*>(h->d_counters + 1);
         P.n_jobs = int(jobs);
+        const bool flat = use_grid && h->grid_info[1] == 1 && h->grid_flat_ok;       // one layer of cells: the walk without a y axis
         int& resident = use_grid ? h->resident_waves_grid : h->resident_waves;
         if (resident <= 0) {
             int per_cu = 0;
-            if (use_grid) PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0));
+            if (use_grid) PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0));   // <2> needs no more
             else PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0));
             hipDeviceProp_t prop;
             PT_HIP(h, hipGetDeviceProperties(&prop, h->device));
@@ -895,7 +898,8 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
             h->ev.push_back(a); h->ev.push_back(b);
         }
         if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
-        if (use_grid) hipLaunchKernelGGL(k_render<1>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        if (flat) hipLaunchKernelGGL(k_render<2>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        else if (use_grid) hipLaunchKernelGGL(k_render<1>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
         else hipLaunchKernelGGL(k_render<0>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
         PT_HIP(h, hipGetLastError());
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
@@ -1017,8 +1021,12 @@ int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, 
     PT_ALLOC_COPY(bp, (void*)nullptr, v3); PT_ALLOC_COPY(bn, (void*)nullptr, v3); PT_ALLOC_COPY(bf, (void*)nullptr, n * sizeof(int));
     if (h->accel == PT_ACCEL_GRID) {
         if (!h->grid_ready) return fail(h, PT_ERR_STATE, "pt_scan: the grid has not been built");
-        hipLaunchKernelGGL(k_scan<1>, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(),
-                           t_min, bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+        if (h->grid_info[1] == 1)
+            hipLaunchKernelGGL(k_scan<2>, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(),
+                               t_min, bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
+        else
+            hipLaunchKernelGGL(k_scan<1>, dim3((n + 63) / 64), dim3(64), 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(),
+                               t_min, bt.as<double>(), bi.as<int>(), bp.as<double>(), bn.as<double>(), bf.as<int>());
     } else {
         GridDev none;
         std::memset(&none, 0, sizeof(none));
