@@ -316,6 +316,21 @@ def test_frame_statistics_T6(dev, scene250):
     sigma = np.sqrt(var.mean())
     assert rmse <= 1.1 * sigma, (rmse, sigma)
     assert abs(rays / (160 * 90 * spp) - float(g["rays_per_sample"])) < 0.01 * float(g["rays_per_sample"])
+    # Bias check: with 16 times the fixture's samples the GPU frame's own noise is negligible, so what is left of
+    # chi^2 is the fixture's noise (1.0) plus any systematic difference; both closest-hit searches.
+    from path_tracer_amd import Device
+    for accel in (0, 1):
+        d2 = Device(0)
+        d2.set_accel(accel); d2.set_scene(sc); d2.set_camera(cam)
+        big = 16 * int(g["spp"])
+        img2, rays2 = d2.render_image(160, 90, big, 50, seed=777)
+        d2.close()
+        m2 = img2.astype(np.float64) / big
+        v2 = g["var"].astype(np.float64) * (1.0 / big + 1.0 / int(g["spp"]))
+        chi2 = ((m2 - g["mean"]) ** 2).sum() / v2.sum()
+        assert 0.93 < chi2 < 1.07, (accel, chi2)
+        assert abs(m2.mean() / lum_ref - 1) < 0.001
+        assert abs(rays2 / (160 * 90 * big) - float(g["rays_per_sample"])) < 0.002 * float(g["rays_per_sample"])
 
 
 def test_depth_zero_empty_range_and_errors(dev, scene250):
