@@ -298,6 +298,31 @@ def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
     assert abs(img.mean() - ref.mean()) < 0.005 * ref.mean() and abs(rays - ref_rays) < 0.01 * ref_rays
 
 
+def test_glass_heavy_scene_statistics(dev, orc):
+    """configs[3] (10 % diffuse, 40 % metal, 50 % glass, depth 100) against the oracle's render with the reference's
+    Mersenne-Twister streams, made here at low resolution: the GPU frame at 64 times the samples has no noise of
+    its own left, so chi^2/N is the oracle's noise (1.0) plus any bias of the device path."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(250, 3, 4, diffuse_below=0.1, metal_below=0.5)
+    cam = host.camera_setup(aspect=80 / 45)
+    W, H, spp_ref, depth = 80, 45, 256, 100
+    hs = orc.scene_create(sc)
+    s, ss, ref_rays = orc.render(hs, cam, W, H, 0, spp_ref, depth, mode=0, seed_a=21, seed_b=22, threads=min(16, os.cpu_count() or 1),
+                                 want_sumsq=True)
+    orc.scene_free(hs)
+    mean_ref = s / spp_ref
+    var_ref = np.maximum(ss / spp_ref - mean_ref ** 2, 0.0) * spp_ref / (spp_ref - 1)      # per-sample variance
+    use(dev, sc, cam)
+    spp = 64 * spp_ref
+    img, rays = dev.render_image(W, H, spp, depth, seed=31)
+    mean = img.astype(np.float64) / spp
+    var = var_ref * (1.0 / spp + 1.0 / spp_ref)
+    chi = ((mean - mean_ref) ** 2).sum() / var.sum()
+    assert 0.9 < chi < 1.1, chi
+    assert abs(mean.mean() / mean_ref.mean() - 1) < 0.005
+    assert abs(rays / (W * H * spp) / (ref_rays / (W * H * spp_ref)) - 1) < 0.01
+
+
 def test_frame_statistics_T6(dev, scene250):
     """T6 as BASELINE states it: against the converged render made with the reference's Mersenne-Twister
     streams (fixture), per-pixel RMSE within the expected sigma at matched spp, mean luminance within 0.5 %."""
