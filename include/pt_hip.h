@@ -89,6 +89,24 @@ int pt_set_camera(pt_handle h, const double position[3], const double lower_left
 int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
               float* accum_rgb_f32, uint64_t* ray_count_out);
 
+/* pt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc). No counterpart in the reference. Same arguments and the same
+ * kernels as pt_render, bit-identical sums, with three differences:
+ *  - the job sums and counters that pt_render keeps in buffers it allocates live in a fixed array inside
+ *    the library (static __device__, 3 x 8 bytes per pixel of the largest image = 49.8 MB on every GPU the
+ *    library runs on, held until the process ends): width*height <= PT_NOALLOC_MAX_PIXELS (1920x1080),
+ *    larger images are rejected with PT_ERR_INVALID;
+ *  - accum_rgb_f32 must be the caller's DEVICE buffer (NULL is rejected); ray_count_dev, when not NULL, is
+ *    a DEVICE pointer that receives the rays traced by this call, written on the handle's stream; the call
+ *    never synchronises and records no kernel time (pt_kernel_times does not see it);
+ *  - every call on one GPU, from any handle, shares that GPU's array: calls that overlap on one GPU race.
+ *    Run them one after the other (one stream, or ordered by events).
+ * It calls no hipMalloc / hipFree / allocating routine; pt_create did the set-up (the array's address on the
+ * handle's device, the occupancy query). */
+#define PT_NOALLOC_MAX_PIXELS (1920 * 1080)
+int pt_render_noalloc(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
+                      float* accum_rgb_f32, uint64_t* ray_count_dev);
+
 /* The handle's own accumulation buffer (zero-filled, width*height*3 floats). */
 int pt_clear_accum(pt_handle h, int width, int height);
 int pt_read_accum(pt_handle h, float* host_f32);   /* replaces reading `pixels` at Path Tracer.cpp:320 */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "pt_accel_info": (C.c_int, [C.c_void_p, _ip, _dp]),
     "pt_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double]),
     "pt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, _u64p]),
+    "pt_render_noalloc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pt_clear_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pt_read_accum": (C.c_int, [C.c_void_p, _fp]),
     "pt_accum_device_ptr": (C.c_void_p, [C.c_void_p]),
@@ -149,6 +150,12 @@ class Device:
                                     C.c_void_p(accum_ptr) if accum_ptr else None,
                                     C.byref(rays) if want_rays else None), "pt_render")
         return int(rays.value) if want_rays else None
+
+    def render_noalloc(self, width, height, spp_begin, spp_end, max_depth, seed, accum_ptr, ray_count_ptr=None):
+        """pt_render for callers that cannot allocate: accum_ptr and ray_count_ptr are DEVICE pointers; asynchronous."""
+        self._ck(self.lib.pt_render_noalloc(self.h, width, height, spp_begin, spp_end, max_depth, seed,
+                                            C.c_void_p(accum_ptr) if accum_ptr else None,
+                                            C.c_void_p(ray_count_ptr) if ray_count_ptr else None), "pt_render_noalloc")
 
     def clear_accum(self, width, height):
         self._ck(self.lib.pt_clear_accum(self.h, width, height), "pt_clear_accum")

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -403,6 +404,15 @@ __global__ void k_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, u
     out[4 * k] = r.x; out[4 * k + 1] = r.y; out[4 * k + 2] = r.z; out[4 * k + 3] = r.w;
 }
 
+// ---- pt_render_noalloc: the job sums and counters of the sample loop in a fixed array ----
+// Device memory the sample loop needs beyond its inputs and outputs: the planar u64[3][H][W] job sums and two
+// counters (rays of the call, next job). pt_render keeps them in buffers it allocates; pt_render_noalloc uses this
+// array instead, one copy per GPU, held until the process ends (PT_NOALLOC_MAX_PIXELS from include/pt_hip.h:
+// 49.8 MB). 32 words of counters, then the sums.
+#define PT_SCRATCH_COUNTER_WORDS 32
+#define PT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned long long scratch[PT_SCRATCH_COUNTER_WORDS + 3 * size_t(PT_NOALLOC_MAX_PIXELS)];
+
 // =============================================================================================
 // Host side: the context and the C-ABI
 // =============================================================================================
@@ -452,6 +462,12 @@ struct pt_context {
 };
 
 static thread_local std::string g_create_err;
+
+// Address of `scratch` on each device (every GPU holds its own copy at its own address), taken once per device in
+// pt_create with that device current. Host code never uses the array's name for anything else: the name is a
+// host-side stand-in, not a device address.
+static std::mutex g_scratch_mutex;
+static unsigned long long* g_scratch_ptr[PT_MAX_DEVICES];
 
 static int fail(pt_handle h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -651,6 +667,29 @@ int pt_create(int device_index, pt_handle* out) {
     e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long));
     if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    // set-up that pt_render_noalloc must not do later: the address of this device's copy of `scratch`, and the
+    // number of waves the device holds at once
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (device_index < PT_MAX_DEVICES && !g_scratch_ptr[device_index]) {
+            unsigned long long* sp = nullptr;
+            e = hipGetSymbolAddress(reinterpret_cast<void**>(&sp), HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !sp) {
+                (void)hipFree(h->d_counters); (void)hipStreamDestroy(h->own_stream); delete h;
+                return fail(nullptr, PT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+            }
+            g_scratch_ptr[device_index] = sp;
+        }
+    }
+    {
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0);
+        if (e != hipSuccess) { (void)hipFree(h->d_counters); (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor: ") + hipGetErrorString(e)); }
+        h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0);      // <2> needs no more
+        if (e != hipSuccess) { (void)hipFree(h->d_counters); (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor: ") + hipGetErrorString(e)); }
+        h->resident_waves_grid = std::max(1, per_cu) * prop.multiProcessorCount;
+    }
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
     if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
@@ -826,31 +865,13 @@ int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* a
     return 0;
 }
 
-int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
-              float* accum_rgb_f32, uint64_t* ray_count_out) {
-    if (!h) return PT_ERR_INVALID;
-    if (!h->have_scene || !h->have_camera) return fail(h, PT_ERR_STATE, "pt_render: set the scene and the camera first");
-    if (width <= 0 || height <= 0 || size_t(width) * size_t(height) > (size_t(1) << 28)) return fail(h, PT_ERR_INVALID, "pt_render: bad image size");
-    if (spp_begin < 0 || spp_end < spp_begin) return fail(h, PT_ERR_INVALID, "pt_render: bad sample range");
-    if (max_depth < 0) return fail(h, PT_ERR_INVALID, "pt_render: negative max_depth");
-    PT_HIP(h, hipSetDevice(h->device));
-    float* out = accum_rgb_f32;
-    if (!out) {
-        if (!h->d_accum || h->acc_w != width || h->acc_h != height) {
-            int rc = pt_clear_accum(h, width, height);
-            if (rc) return rc;
-        }
-        out = h->d_accum;
-    }
+// The sample loop of one call, shared by pt_render and pt_render_noalloc: clears the two call counters, launches
+// k_render on the handle's stream (sums into fx, which must be zero), then k_resolve (fx -> out, fx back to zero).
+// Allocates nothing unless `timed` needs a new pair of events. counters: [0] rays of the call, [1] next job.
+static int render_core(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed, float* out,
+                       unsigned long long* fx, unsigned long long* counters, bool timed) {
     const size_t n_elems = size_t(width) * height * 3;
-    if (h->fx_elems < n_elems) {
-        PT_HIP(h, hipStreamSynchronize(h->stream));
-        if (h->d_fx) { PT_HIP(h, hipFree(h->d_fx)); h->d_fx = nullptr; h->fx_elems = 0; }
-        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_fx), n_elems * sizeof(unsigned long long)));
-        PT_HIP(h, hipMemsetAsync(h->d_fx, 0, n_elems * sizeof(unsigned long long), h->stream));
-        h->fx_elems = n_elems;
-    }
-    PT_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    PT_HIP(h, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), h->stream));
     const int spp = spp_end - spp_begin;
     if (spp > 0) {
         RenderParams P;
@@ -876,22 +897,14 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         const bool use_grid = h->accel == PT_ACCEL_GRID;
         if (use_grid && !h->grid_ready) return fail(h, PT_ERR_STATE, "pt_render: the grid has not been built");
         if (use_grid) P.grid = h->grid; else std::memset(&P.grid, 0, sizeof(P.grid));
-        P.accum_fx = h->d_fx;
-        P.ray_count = h->d_counters;
-        P.job_counter = reinterpret_cast<unsigned int*>(h->d_counters + 1);
+        P.accum_fx = fx;
+        P.ray_count = counters;
+        P.job_counter = reinterpret_cast<unsigned int*>(counters + 1);
         P.n_jobs = int(jobs);
         const bool flat = use_grid && h->grid_info[1] == 1 && h->grid_flat_ok;       // one layer of cells: the walk without a y axis
-        int& resident = use_grid ? h->resident_waves_grid : h->resident_waves;
-        if (resident <= 0) {
-            int per_cu = 0;
-            if (use_grid) PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0));   // <2> needs no more
-            else PT_HIP(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0));
-            hipDeviceProp_t prop;
-            PT_HIP(h, hipGetDeviceProperties(&prop, h->device));
-            resident = std::max(1, per_cu) * prop.multiProcessorCount;
-        }
+        const int resident = use_grid ? h->resident_waves_grid : h->resident_waves;   // from pt_create
         const long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
-        const bool timed = h->ev_used + 2 <= 8192;
+        timed = timed && h->ev_used + 2 <= 8192;
         if (timed && h->ev.size() < h->ev_used + 2) {
             hipEvent_t a, b;
             PT_HIP(h, hipEventCreate(&a)); PT_HIP(h, hipEventCreate(&b));
@@ -907,9 +920,42 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
     {
         const size_t n_pixels = n_elems / 3;
         const unsigned blocks = unsigned(std::min<size_t>((n_pixels + 255) / 256, 256 * 16));
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, h->d_fx, out, n_pixels, h->d_counters, h->d_counters + 2);
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, fx, out, n_pixels, counters, h->d_counters + 2);
         PT_HIP(h, hipGetLastError());
     }
+    return 0;
+}
+
+static int check_render_args(pt_handle h, const char* who, int width, int height, int spp_begin, int spp_end, int max_depth) {
+    if (!h->have_scene || !h->have_camera) return fail(h, PT_ERR_STATE, std::string(who) + ": set the scene and the camera first");
+    if (width <= 0 || height <= 0 || size_t(width) * size_t(height) > (size_t(1) << 28)) return fail(h, PT_ERR_INVALID, std::string(who) + ": bad image size");
+    if (spp_begin < 0 || spp_end < spp_begin) return fail(h, PT_ERR_INVALID, std::string(who) + ": bad sample range");
+    if (max_depth < 0) return fail(h, PT_ERR_INVALID, std::string(who) + ": negative max_depth");
+    return 0;
+}
+
+int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
+              float* accum_rgb_f32, uint64_t* ray_count_out) {
+    if (!h) return PT_ERR_INVALID;
+    if (int rc = check_render_args(h, "pt_render", width, height, spp_begin, spp_end, max_depth)) return rc;
+    PT_HIP(h, hipSetDevice(h->device));
+    float* out = accum_rgb_f32;
+    if (!out) {
+        if (!h->d_accum || h->acc_w != width || h->acc_h != height) {
+            int rc = pt_clear_accum(h, width, height);
+            if (rc) return rc;
+        }
+        out = h->d_accum;
+    }
+    const size_t n_elems = size_t(width) * height * 3;
+    if (h->fx_elems < n_elems) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_fx) { PT_HIP(h, hipFree(h->d_fx)); h->d_fx = nullptr; h->fx_elems = 0; }
+        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_fx), n_elems * sizeof(unsigned long long)));
+        PT_HIP(h, hipMemsetAsync(h->d_fx, 0, n_elems * sizeof(unsigned long long), h->stream));
+        h->fx_elems = n_elems;
+    }
+    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, out, h->d_fx, h->d_counters, true)) return rc;
 #ifdef PT_STATS
     {
         unsigned long long st[8];
@@ -929,6 +975,28 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         PT_HIP(h, hipStreamSynchronize(h->stream));
         *ray_count_out = v;
     }
+    return 0;
+}
+
+int pt_render_noalloc(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed,
+                      float* accum_rgb_f32, uint64_t* ray_count_dev) {
+    if (!h) return PT_ERR_INVALID;
+    if (int rc = check_render_args(h, "pt_render_noalloc", width, height, spp_begin, spp_end, max_depth)) return rc;
+    if (!accum_rgb_f32) return fail(h, PT_ERR_INVALID, "pt_render_noalloc: the caller passes the accumulation buffer (a device pointer)");
+    if (size_t(width) * size_t(height) > size_t(PT_NOALLOC_MAX_PIXELS))
+        return fail(h, PT_ERR_INVALID, "pt_render_noalloc: image of " + std::to_string(width) + "x" + std::to_string(height) +
+                                           " exceeds the fixed job-sum array (" + std::to_string(PT_NOALLOC_MAX_PIXELS) +
+                                           " pixels, 1920x1080); use pt_render");
+    unsigned long long* sp = h->device < PT_MAX_DEVICES ? g_scratch_ptr[h->device] : nullptr;     // set by pt_create on this device
+    if (!sp) return fail(h, PT_ERR_STATE, "pt_render_noalloc: no scratch address for this device");
+    PT_HIP(h, hipSetDevice(h->device));
+    // The array keeps whatever the last call on this GPU left (k_resolve leaves the sums it read at zero, but a call
+    // that failed half-way would not): clear the part this call uses.
+    const size_t n_elems = size_t(width) * height * 3;
+    unsigned long long* fx = sp + PT_SCRATCH_COUNTER_WORDS;
+    PT_HIP(h, hipMemsetAsync(fx, 0, n_elems * sizeof(unsigned long long), h->stream));
+    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, accum_rgb_f32, fx, sp, false)) return rc;
+    if (ray_count_dev) PT_HIP(h, hipMemcpyAsync(ray_count_dev, sp, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
