@@ -109,7 +109,9 @@ int pt_render_noalloc(pt_handle h, int width, int height, int spp_begin, int spp
 
 /* The handle's own accumulation buffer (zero-filled, width*height*3 floats). */
 int pt_clear_accum(pt_handle h, int width, int height);
-int pt_read_accum(pt_handle h, float* host_f32);   /* replaces reading `pixels` at Path Tracer.cpp:320 */
+/* Copies the handle's buffer to host_f32 (replaces reading `pixels` at Path Tracer.cpp:320). width and height
+ * state the size of the caller's array: PT_ERR_INVALID unless they are the buffer's own. */
+int pt_read_accum(pt_handle h, int width, int height, float* host_f32);
 void* pt_accum_device_ptr(pt_handle h);
 
 /* Upload a saved accumulation buffer (width*height*3 floats, top row first) into the handle's own
@@ -135,6 +137,10 @@ int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n);
  * with an RCCL reduce. No counterpart in the reference, which shares one vector between threads
  * (Path Tracer.cpp:292); comes from the spp split of the frame across GPUs. */
 int pt_reduce(pt_handle* handles, int n, int root);
+/* The RCCL library and the communicators are set up on the first pt_reduce and kept for the same device list
+ * (destroyed when the list changes or the last handle goes). One handle per device; two handles on one device
+ * are rejected. comm_inits = communicator set-ups made so far, cached_ranks = ranks of the set in use. */
+int pt_reduce_stats(int* comm_inits, int* cached_ranks);
 
 /* ---- Unit-test entry points: the device functions of the sample loop, one call per batch. ---- */
 

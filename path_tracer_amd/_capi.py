@@ -30,13 +30,14 @@ SIGNATURES = {
     "pt_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, _u64p]),
     "pt_render_noalloc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "pt_clear_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "pt_read_accum": (C.c_int, [C.c_void_p, _fp]),
+    "pt_read_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "pt_accum_device_ptr": (C.c_void_p, [C.c_void_p]),
     "pt_write_accum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "pt_quantise_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8)]),
     "pt_ray_count": (C.c_int, [C.c_void_p, _u64p]),
     "pt_kernel_times": (C.c_int, [C.c_void_p, _fp, C.c_int, _ip]),
     "pt_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "pt_reduce_stats": (C.c_int, [_ip, _ip]),
     "pt_scan": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_double, _dp, _ip, _dp, _dp, _ip]),
     "pt_scatter": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _ip]),
     "pt_gen_ray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -163,7 +164,7 @@ class Device:
 
     def read_accum(self, width, height):
         out = np.zeros((height, width, 3), dtype=np.float32)
-        self._ck(self.lib.pt_read_accum(self.h, _p(out, _fp)), "pt_read_accum")
+        self._ck(self.lib.pt_read_accum(self.h, width, height, _p(out, _fp)), "pt_read_accum")
         return out
 
     def write_accum(self, sums):
@@ -242,3 +243,20 @@ class Device:
         out = np.zeros_like(ctr)
         self._ck(self.lib.pt_philox(self.h, ctr.shape[0], _p(ctr, _up), _p(key, _up), _p(out, _up)), "pt_philox")
         return out
+
+
+def reduce(devices, root=0):
+    """pt_reduce: sums the own accumulation buffers of `devices` (one Device per GPU, this process) into devices[root]."""
+    lib = load_library()
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    rc = lib.pt_reduce(arr, len(devices), root)
+    if rc != 0:
+        raise PtError("pt_reduce failed (%d): %s" % (rc, lib.pt_last_error(devices[0].h).decode()))
+
+
+def reduce_stats():
+    """(communicator set-ups made so far, ranks of the cached set)."""
+    lib = load_library()
+    a, b = C.c_int(0), C.c_int(0)
+    lib.pt_reduce_stats(C.byref(a), C.byref(b))
+    return a.value, b.value

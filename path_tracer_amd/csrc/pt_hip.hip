@@ -452,6 +452,8 @@ struct pt_context {
     size_t fx_elems = 0;
     float* d_accum = nullptr;
     int acc_w = 0, acc_h = 0;
+    unsigned char* d_rgb8 = nullptr;            // output stage (pt_quantise_rgb8): kept between frames, grows only
+    size_t rgb8_cap = 0;
     unsigned long long* d_counters = nullptr;   // [0] rays of the current call, [1] job counter, [2] rays since creation
     int resident_waves = 0;                     // waves the device holds at once (persistent grid size)
     // kernel timing
@@ -640,6 +642,9 @@ static int build_grid(pt_handle h) {
     return 0;
 }
 
+static void rccl_handle_created();
+static void rccl_handle_destroyed();
+
 extern "C" {
 
 const char* pt_last_error(pt_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -695,6 +700,7 @@ int pt_create(int device_index, pt_handle* out) {
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
     if (const char* gf = std::getenv("PT_GRID_FLAT")) h->grid_flat_ok = std::atoi(gf) != 0;
     if (const char* br = std::getenv("PT_GRID_BIG_RATIO")) { double v = std::atof(br); if (v >= 1 && v < 1e6) h->grid_big_ratio = v; }
+    rccl_handle_created();
     *out = h;
     return 0;
 }
@@ -705,11 +711,12 @@ int pt_destroy(pt_handle h) {
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
-    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam);
+    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam); (void)hipFree(h->d_rgb8);
     (void)hipFree(h->d_cell_start); (void)hipFree(h->d_items); (void)hipFree(h->d_item_ids);
     (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan); (void)hipFree(h->d_grid_shape);
     (void)hipStreamDestroy(h->own_stream);
     delete h;
+    rccl_handle_destroyed();
     return 0;
 }
 
@@ -826,9 +833,12 @@ int pt_clear_accum(pt_handle h, int width, int height) {
 
 void* pt_accum_device_ptr(pt_handle h) { return h ? h->d_accum : nullptr; }
 
-int pt_read_accum(pt_handle h, float* host_f32) {
+int pt_read_accum(pt_handle h, int width, int height, float* host_f32) {
     if (!h || !host_f32) return PT_ERR_INVALID;
     if (!h->d_accum) return fail(h, PT_ERR_STATE, "pt_read_accum: no accumulation buffer (call pt_clear_accum or pt_render first)");
+    if (width != h->acc_w || height != h->acc_h)
+        return fail(h, PT_ERR_INVALID, "pt_read_accum: the caller's array is " + std::to_string(width) + "x" + std::to_string(height) +
+                                           " but the buffer is " + std::to_string(h->acc_w) + "x" + std::to_string(h->acc_h));
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipMemcpyAsync(host_f32, h->d_accum, size_t(h->acc_w) * h->acc_h * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -855,12 +865,16 @@ int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* a
     }
     PT_HIP(h, hipSetDevice(h->device));
     const size_t n = size_t(width) * height * 3;
-    DevBuf out;
-    PT_HIP(h, out.alloc(n));
+    if (h->rgb8_cap < n) {
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_rgb8) { PT_HIP(h, hipFree(h->d_rgb8)); h->d_rgb8 = nullptr; h->rgb8_cap = 0; }
+        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_rgb8), n));
+        h->rgb8_cap = n;
+    }
     const unsigned blocks = unsigned(std::min<size_t>((n + 255) / 256, 256 * 16));
-    hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, h->stream, src, n, 1.0 / double(spp), out.as<unsigned char>());
+    hipLaunchKernelGGL(k_quantise, dim3(blocks), dim3(256), 0, h->stream, src, n, 1.0 / double(spp), h->d_rgb8);
     PT_HIP(h, hipGetLastError());
-    PT_HIP(h, hipMemcpyAsync(host_rgb8, out.p, n, hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipMemcpyAsync(host_rgb8, h->d_rgb8, n, hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1022,48 +1036,110 @@ int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n) {
 }
 
 // ---- RCCL reduce of the own accumulation buffers, single process, one handle per GPU ----
+// librccl is loaded once and the communicators are kept for the device list they were made for (set-up costs
+// hundreds of milliseconds, a reduce of a 1080p frame well under one); they are destroyed when the device list
+// changes and when the last handle of the process is destroyed.
+}   // extern "C"
+
+namespace {
+typedef void* comm_t;
+struct RcclState {
+    std::mutex mutex;
+    void* lib = nullptr;
+    int (*init_all)(comm_t*, int, const int*) = nullptr;
+    int (*reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*comm_destroy)(comm_t) = nullptr;
+    int (*comm_abort)(comm_t) = nullptr;
+    std::vector<int> devices;          // device of each rank of the cached communicators
+    std::vector<comm_t> comms;
+    int inits = 0;                     // ncclCommInitAll calls made so far (pt_reduce_stats)
+    int live_handles = 0;
+    void drop(bool abort) {            // mutex held
+        for (comm_t c : comms) if (c) (void)((abort && comm_abort) ? comm_abort(c) : comm_destroy(c));
+        comms.clear(); devices.clear();
+    }
+};
+RcclState g_rccl;
+}   // namespace
+
+static void rccl_handle_created() { std::lock_guard<std::mutex> lock(g_rccl.mutex); ++g_rccl.live_handles; }
+static void rccl_handle_destroyed() {
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (--g_rccl.live_handles <= 0 && !g_rccl.comms.empty()) g_rccl.drop(false);
+}
+
+extern "C" {
+
 int pt_reduce(pt_handle* handles, int n, int root) {
     if (!handles || n <= 0 || root < 0 || root >= n) return PT_ERR_INVALID;
+    for (int i = 0; i < n; ++i) if (!handles[i]) return PT_ERR_INVALID;
+    pt_handle h0 = handles[0];
     for (int i = 0; i < n; ++i) {
-        if (!handles[i] || !handles[i]->d_accum) return fail(handles[0], PT_ERR_STATE, "pt_reduce: a handle has no accumulation buffer");
-        if (handles[i]->acc_w != handles[0]->acc_w || handles[i]->acc_h != handles[0]->acc_h)
-            return fail(handles[0], PT_ERR_INVALID, "pt_reduce: accumulation buffers differ in size");
+        if (!handles[i]->d_accum) return fail(h0, PT_ERR_STATE, "pt_reduce: a handle has no accumulation buffer");
+        if (handles[i]->acc_w != h0->acc_w || handles[i]->acc_h != h0->acc_h)
+            return fail(h0, PT_ERR_INVALID, "pt_reduce: accumulation buffers differ in size");
+        for (int k = 0; k < i; ++k)
+            if (handles[k]->device == handles[i]->device)
+                return fail(h0, PT_ERR_INVALID, "pt_reduce: two handles on device " + std::to_string(handles[i]->device) +
+                                                    " (one handle per GPU: RCCL takes one rank per device)");
     }
     if (n == 1) return 0;
-    pt_handle h0 = handles[0];
-    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) return fail(h0, PT_ERR_RCCL, std::string("pt_reduce: cannot load librccl: ") + dlerror());
-    typedef void* comm_t;
-    typedef int (*init_all_t)(comm_t*, int, const int*);
-    typedef int (*reduce_t)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t);
-    typedef int (*void_t)();
-    typedef int (*destroy_t)(comm_t);
-    init_all_t init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
-    reduce_t reduce = (reduce_t)dlsym(lib, "ncclReduce");
-    void_t gstart = (void_t)dlsym(lib, "ncclGroupStart");
-    void_t gend = (void_t)dlsym(lib, "ncclGroupEnd");
-    destroy_t destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
-    if (!init_all || !reduce || !gstart || !gend || !destroy) return fail(h0, PT_ERR_RCCL, "pt_reduce: librccl lacks an expected symbol");
-    std::vector<comm_t> comms(n);
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    RcclState& R = g_rccl;
+    if (!R.lib) {
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(h0, PT_ERR_RCCL, std::string("pt_reduce: cannot load librccl: ") + dlerror());
+        R.init_all = reinterpret_cast<decltype(R.init_all)>(dlsym(lib, "ncclCommInitAll"));
+        R.reduce = reinterpret_cast<decltype(R.reduce)>(dlsym(lib, "ncclReduce"));
+        R.group_start = reinterpret_cast<decltype(R.group_start)>(dlsym(lib, "ncclGroupStart"));
+        R.group_end = reinterpret_cast<decltype(R.group_end)>(dlsym(lib, "ncclGroupEnd"));
+        R.comm_destroy = reinterpret_cast<decltype(R.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+        R.comm_abort = reinterpret_cast<decltype(R.comm_abort)>(dlsym(lib, "ncclCommAbort"));      // optional
+        if (!R.init_all || !R.reduce || !R.group_start || !R.group_end || !R.comm_destroy) {
+            (void)dlclose(lib);
+            return fail(h0, PT_ERR_RCCL, "pt_reduce: librccl lacks an expected symbol");
+        }
+        R.lib = lib;
+    }
     std::vector<int> devs(n);
     for (int i = 0; i < n; ++i) devs[i] = handles[i]->device;
-    if (init_all(comms.data(), n, devs.data()) != 0) return fail(h0, PT_ERR_RCCL, "pt_reduce: ncclCommInitAll failed");
-    const size_t count = size_t(h0->acc_w) * h0->acc_h * 3;
-    int rc = 0;
-    const int ncclFloat32 = 7, ncclSum = 0;
-    if (gstart() != 0) rc = PT_ERR_RCCL;
-    for (int i = 0; i < n && !rc; ++i) {
-        (void)hipSetDevice(handles[i]->device);
-        if (reduce(handles[i]->d_accum, handles[i]->d_accum, count, ncclFloat32, ncclSum, root, comms[i], handles[i]->stream) != 0) rc = PT_ERR_RCCL;
+    if (devs != R.devices) {
+        R.drop(false);
+        std::vector<comm_t> comms(n, nullptr);
+        ++R.inits;
+        if (R.init_all(comms.data(), n, devs.data()) != 0) return fail(h0, PT_ERR_RCCL, "pt_reduce: ncclCommInitAll failed");
+        R.comms = comms; R.devices = devs;
     }
-    if (gend() != 0) rc = PT_ERR_RCCL;
+    // The reduce runs on each handle's stream, after that handle's renders; each handle is idle otherwise
+    // (one host thread per handle at a time, as everywhere in this library).
+    const size_t count = size_t(h0->acc_w) * h0->acc_h * 3;
+    const int ncclFloat32 = 7, ncclSum = 0;
+    int bad = 0;
+    if (R.group_start() != 0) return fail(h0, PT_ERR_RCCL, "pt_reduce: ncclGroupStart failed");
+    for (int i = 0; i < n && !bad; ++i) {
+        (void)hipSetDevice(handles[i]->device);
+        if (R.reduce(handles[i]->d_accum, handles[i]->d_accum, count, ncclFloat32, ncclSum, root, R.comms[i], handles[i]->stream) != 0) bad = 1;
+    }
+    if (R.group_end() != 0) bad = 1;
+    if (bad) {
+        R.drop(true);                                      // abort rather than wait for a collective that will not complete
+        return fail(h0, PT_ERR_RCCL, "pt_reduce: ncclReduce failed");
+    }
     for (int i = 0; i < n; ++i) {
         (void)hipSetDevice(handles[i]->device);
-        (void)hipStreamSynchronize(handles[i]->stream);
-        (void)destroy(comms[i]);
+        hipError_t e = hipStreamSynchronize(handles[i]->stream);
+        if (e != hipSuccess) { R.drop(true); return fail(h0, PT_ERR_HIP, std::string("pt_reduce: hipStreamSynchronize: ") + hipGetErrorString(e)); }
     }
-    if (rc) return fail(h0, rc, "pt_reduce: ncclReduce failed");
+    return 0;
+}
+
+int pt_reduce_stats(int* comm_inits, int* cached_ranks) {
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (comm_inits) *comm_inits = g_rccl.inits;
+    if (cached_ranks) *cached_ranks = int(g_rccl.comms.size());
     return 0;
 }
 

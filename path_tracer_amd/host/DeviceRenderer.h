@@ -58,7 +58,7 @@ public:
     // The sums, top row first, as the reference's `pixels` (Path Tracer.cpp:292-298).
     std::vector<PhysicsVector<3>> pixels() {
         std::vector<float> f(std::size_t(m_width) * m_height * 3);
-        check(pt_read_accum(m_handle, f.data()), "pt_read_accum");
+        check(pt_read_accum(m_handle, m_width, m_height, f.data()), "pt_read_accum");
         std::vector<PhysicsVector<3>> out(std::size_t(m_width) * m_height);
         for (std::size_t i = 0; i < out.size(); ++i) out[i] = PhysicsVector<3>{f[3 * i], f[3 * i + 1], f[3 * i + 2]};
         check(pt_ray_count(m_handle, &m_rays), "pt_ray_count");
@@ -77,7 +77,12 @@ public:
         check(pt_write_accum(m_handle, width, height, sums.data()), "pt_write_accum");
         m_width = width; m_height = height;
     }
-    std::uint64_t raysTraced() const { return m_rays; }
+    // Rays traced since the renderer was created (synchronises with the device).
+    std::uint64_t raysTraced() {
+        check(pt_ray_count(m_handle, &m_rays), "pt_ray_count");
+        return m_rays;
+    }
+    void synchronize() { check(pt_synchronize(m_handle), "pt_synchronize"); }
 
     // Milliseconds the sample-loop kernel ran for, summed over the renders since the last call.
     double kernelMilliseconds() {

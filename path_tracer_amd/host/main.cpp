@@ -41,27 +41,45 @@ int main(int argc, char** argv) {
             devs.back()->setCamera(camera);
             devs.back()->begin(width, height);
         }
+        std::vector<pt_handle> hs;
+        for (auto& d : devs) hs.push_back(d->handle());
+        auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+        double setupSeconds = 0;
+        if (gpus > 1) {
+            // Communicator set-up (hundreds of milliseconds, once per process) is not part of the frame: the buffers are
+            // still all zero here, so summing them changes nothing and leaves the communicators ready.
+            const auto ts = std::chrono::steady_clock::now();
+            if (pt_reduce(hs.data(), gpus, 0) != 0) throw dp::DeviceError(std::string("pt_reduce: ") + pt_last_error(hs[0]));
+            setupSeconds = since(ts);
+        }
         const auto t0 = std::chrono::steady_clock::now();
         for (int g = 0; g < gpus; ++g) {
             const int b = int((long long)s.raysPerPixel * g / gpus), e = int((long long)s.raysPerPixel * (g + 1) / gpus);
             devs[g]->accumulate(b, e, s.materialMaxDepth, s.renderSeed);
         }
-        if (gpus > 1) {
-            std::vector<pt_handle> hs;
-            for (auto& d : devs) hs.push_back(d->handle());
-            if (pt_reduce(hs.data(), gpus, 0) != 0) throw dp::DeviceError(std::string("pt_reduce: ") + pt_last_error(hs[0]));
-        }
+        for (auto& d : devs) d->synchronize();
+        const double renderSeconds = since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (gpus > 1 && pt_reduce(hs.data(), gpus, 0) != 0) throw dp::DeviceError(std::string("pt_reduce: ") + pt_last_error(hs[0]));
+        const double reduceSeconds = since(t1);
+        const auto t2 = std::chrono::steady_clock::now();
         const std::vector<unsigned char> bytes = devs[0]->quantised(s.raysPerPixel);   // output stage on the device
-        const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double outputSeconds = since(t2);
+        const double seconds = since(t0);
         std::uint64_t rays = 0;
-        for (auto& d : devs) { (void)d->quantised(s.raysPerPixel); rays += d->raysTraced(); }
+        for (auto& d : devs) rays += d->raysTraced();
         const double samples = double(width) * height * s.raysPerPixel;
         std::cout << "Rendered " << width << "x" << height << " at " << s.raysPerPixel << " spp on " << gpus << " GPU(s) in " << seconds
-                  << " s: " << samples / seconds / 1e6 << " Msamples/s, " << double(rays) / seconds / 1e9 << " Grays/s\n";
+                  << " s: " << samples / seconds / 1e6 << " Msamples/s, " << double(rays) / seconds / 1e9 << " Grays/s"
+                  << " (render " << renderSeconds << " s, reduce " << reduceSeconds << " s, gamma+quantise+read-back " << outputSeconds
+                  << " s; communicator set-up before the frame " << setupSeconds << " s)\n";
 
+        const auto t3 = std::chrono::steady_clock::now();
         std::ofstream out(outPath, std::ios::out | std::ios::binary);
         if (s.binaryOutput) dp::writeImageP6(out, bytes, width, height);
         else dp::writeImageP3(out, bytes, width, height);                               // byte for byte the reference's file
+        out.close();
+        std::cout << "Wrote " << outPath << " (" << (s.binaryOutput ? "P6" : "P3") << ") in " << since(t3) << " s\n";
     } catch (const std::exception& e) {
         std::cerr << "pathtracer: " << e.what() << '\n';
         return 1;
