@@ -236,6 +236,68 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     best_t -= shift;                             // back to the ray's own (approximate) t; inf stays inf
 }
 
+// The same search with the SPHERES spread over a GROUP of G lanes that all hold the same ray (every argument the
+// same in the lanes of a group; a wave holds 64 / G rays): lane `sub` of the group tests quads sub, sub + G, ..., then
+// the group's candidates are reduced to the closest hit, ties to the later index. The per-sphere arithmetic is that of
+// scan_quad and tier2 operation for operation, and the rule "smallest t, then largest index" does not depend on the
+// order of the comparisons, so the answer is bit for bit the one scan_spheres gives. Used by k_tail for the long
+// paths left at the end of a frame, where latency counts and most of the chip is idle.
+template <int G>
+PT_DEV void coop_scan(const SceneDev& sc, int sub, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+    const float od = dot(o, dh);
+    const f3 p = fma3(dh, -od, o);
+    const float ne = -dot(p, dh);
+    const f3 p2 = p * 2.0f;
+    const float pp = dot(p, p);
+    const float shift = od;
+    tmin += shift;
+    self_t += shift;
+    best_t = __builtin_inff();
+    best_i = -1;
+    const int n_quads = sc.n_pad >> 2;
+    for (int q = sub; q < n_quads; q += G) {
+        const float4* rec = reinterpret_cast<const float4*>(sc.scan + 16 * size_t(q));
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const float R[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v2f cx = v2f{R[8 * h + 0], R[8 * h + 1]}, cy = v2f{R[8 * h + 2], R[8 * h + 3]};
+            const v2f cz = v2f{R[8 * h + 4], R[8 * h + 5]}, nK = v2f{R[8 * h + 6], R[8 * h + 7]};
+            v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{ne, ne});
+            b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
+            b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
+            v2f u = __builtin_elementwise_fma(b, b, nK);
+            u = __builtin_elementwise_fma(cx, v2f{p2.x, p2.x}, u);
+            u = __builtin_elementwise_fma(cy, v2f{p2.y, p2.y}, u);
+            u = __builtin_elementwise_fma(cz, v2f{p2.z, p2.z}, u);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = 4 * q + 2 * h + k;
+                const float s = fast_sqrt(u[k] - pp);              // NaN for a line that misses: every compare below is false
+                const float t1 = b[k] - s, t2 = b[k] + s;
+                const float t = (t1 >= tmin) ? t1 : t2;
+                const bool ok = (j != prev) & (t >= tmin) & (t <= best_t);   // j rises within a lane: <= keeps the later index
+                best_t = ok ? t : best_t;
+                best_i = ok ? j : best_i;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = G / 2; s > 0; s >>= 1) {
+        const float ot = __shfl_xor(best_t, s);
+        const int oi = __shfl_xor(best_i, s);
+        const bool take = (ot < best_t) | ((ot == best_t) & (oi > best_i));
+        best_t = take ? ot : best_t;
+        best_i = take ? oi : best_i;
+    }
+    {
+        bool ok = (prev >= 0) & (self_t >= tmin) & (self_t <= best_t);
+        best_t = ok ? self_t : best_t;
+        best_i = ok ? prev : best_i;
+    }
+    best_t -= shift;
+}
+
 // Far root of the sphere a scattered ray starts on. The start point p lies on it, so
 // c - p = -r * n_out with n_out = front ? n : -n, and the roots of the unit-direction quadratic
 // are 0 and 2 (c - p).dh = -+ 2 r (n.dh).

@@ -34,6 +34,15 @@ using namespace ptd;
 // =============================================================================================
 // Device side
 // =============================================================================================
+#define PT_COUNTER_WORDS 8
+struct TailPath {                    // a path handed from k_render to k_tail: the ray it is about to trace and what it carries
+    float o[3], dh[3], thr[3];
+    float len, self_t;
+    int prev, bounce;                // bounce < 0: empty slot
+    uint32_t pixel, sample, top_pixel;
+};
+static_assert(sizeof(TailPath) == 64, "TailPath is 16 words");
+
 struct RenderParams {
     int W, H;
     int spp_begin, spp_end, spp_chunk, n_chunks;
@@ -46,9 +55,16 @@ struct RenderParams {
     SceneDev scene;
     GridDev grid;                    // read by k_render<1> and k_render<2> only
     unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
-    unsigned long long* ray_count;   // rays of this call
-    unsigned int* job_counter;       // next job to hand out, zero at launch
+    // One block of device memory, 8 x u64 of counters and then the slots through which k_render<0> hands paths to
+    // k_tail (PT_TAIL_PATHS slots per wave of the launch): [0] rays of this call; [1] next job to hand out (u32; the
+    // launch sets it to the number of waves, whose first jobs are their own numbers). One pointer instead of three:
+    // the scan leaves no scalar register to spare.
+    unsigned long long* counters;
+    int n_tail_slots;                // k_tail only: slots written by the k_render launch before it
 };
+PT_DEV unsigned long long* ray_counter(const RenderParams& P) { return P.counters; }
+PT_DEV unsigned int* job_counter(const RenderParams& P) { return reinterpret_cast<unsigned int*>(P.counters + 1); }
+PT_DEV TailPath* tail_slots(const RenderParams& P) { return reinterpret_cast<TailPath*>(P.counters + PT_COUNTER_WORDS); }
 
 // A CameraDev from its 19 floats in device memory; the constant address space makes hipcc use scalar loads
 // although the kernel also contains atomics.
@@ -65,9 +81,10 @@ PT_DEV CameraDev load_camera(const float* p) {
 // Radiance in [0, 1] per channel (every attenuation and the sky are <= 1) to unsigned Q32.32.
 // Integer sums make the frame independent of the order in which lanes and jobs finish.
 PT_DEV unsigned long long to_fx(float v) {
-    v = (v >= 0.0f) ? v : 0.0f;          // also drops a NaN
-    v = __builtin_fminf(v, 65536.0f);
-    return (unsigned long long)(v * 4294967296.0f);
+    v = __builtin_fmaxf(v, 0.0f);                                   // also drops a NaN (maxnum returns the number)
+    const uint32_t hi = uint32_t(v);                                 // whole part: the conversion truncates and saturates
+    const uint32_t lo = uint32_t(__builtin_amdgcn_fractf(v) * 4294967296.0f);   // fraction, exact (a power-of-two scale), truncated
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 #ifdef PT_STATS
@@ -88,7 +105,11 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const unsigned long long v = bank[lane * 3 + c];
+#ifndef PT_EXP_NOFLUSH
             if (v) atomicAdd(dst + c * plane, v);
+#else
+            if (v == 1234567) atomicAdd(dst + c * plane, v);
+#endif
         }
     }
     bank[lane * 3 + 0] = 0; bank[lane * 3 + 1] = 0; bank[lane * 3 + 2] = 0;
@@ -105,15 +126,20 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #ifndef PT_GRID_WAVES_PER_EU
 #define PT_GRID_WAVES_PER_EU 5      // 96 registers, no spills; at 8 waves (64) the walk state spills and the kernel runs at half the speed
 #endif
+#ifndef PT_TAIL_PATHS
+#define PT_TAIL_PATHS 6             // a wave left with at most this many paths and no job hands them to k_tail
+#endif
 #ifndef PT_GRID_RATIO
 #define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER_EU) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[2 * 192];
+    __shared__ unsigned int wave_number;            // blockIdx.x, parked in LDS until the end of the kernel: the loop has no scalar register for it
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[lane + 64 * i] = 0;
+    if (lane == 0) wave_number = blockIdx.x;
 
     // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining
     int parity = 0;
@@ -141,6 +167,11 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     // record; lanes whose path ended take a new (sample, pixel) item; ONE philox block per lane then
     // feeds either the camera ray of a new path (bounce 0) or the scatter of a continuing one.
     for (;;) {
+        if constexpr (MODE == 0) {
+            // End of the frame: no job is left and this wave holds only a few paths (the long ones). They are finished
+            // below, one at a time, with the spheres spread over the lanes.
+            if (no_more_jobs && __popcll(__ballot(active)) <= PT_TAIL_PATHS) break;
+        }
         HitRec h;
         MatRec mat;
         bool hit = false;
@@ -206,9 +237,14 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 // stragglers add their result straight to the frame when they end (integer sums: any order).
                 if (active && lbank != parity) lbank = 2;
                 if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
-                int job = 0;
-                if (lane == 0) job = int(atomicAdd(P.job_counter, 1u));
-                job = __builtin_amdgcn_readfirstlane(job);
+                // the index asked for when the previous job began (the round trip to the counter takes microseconds)
+                // A wave's first job is its own number (the launch has at most as many waves as jobs); the counter hands
+                // out the rest. Thousands of waves asking one address at the same moment would queue for ~0.1 ms.
+                int job = int(blockIdx.x);
+                if (c_valid) {
+                    if (lane == 0) job = int(atomicAdd(job_counter(P), 1u));
+                    job = __builtin_amdgcn_readfirstlane(job);
+                }
                 if (job >= P.n_jobs) { no_more_jobs = true; break; }
                 o_tx = c_tx; o_ty = c_ty; o_valid = c_valid;
                 parity ^= 1;
@@ -243,8 +279,8 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             }
         }
         if (!__any(active)) {
-            if (no_more_jobs) break;
-            continue;
+            if constexpr (MODE != 0) { if (no_more_jobs) break; }
+            continue;                                        // MODE 0: the check at the top of the loop ends the wave
         }
         { const int live = __popcll(__ballot(MODE == 0 ? active : (active && !walking))); (void)live;
           PT_STAT_ADD(0, 1);                                 // wave-level ray segments
@@ -293,13 +329,103 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
         }
     }
 
+    // ---- the last few paths of this wave go to its slots for k_tail (tail of the frame); the other slots are marked empty ----
+    if constexpr (MODE == 0) {
+        const unsigned long long live = __ballot(active);
+        const int n_live = __popcll(live);
+        const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(live >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(live), 0));
+        TailPath* slots = tail_slots(P) + size_t(wave_number) * PT_TAIL_PATHS;
+        if (active) {
+            TailPath tp;
+            tp.o[0] = o.x; tp.o[1] = o.y; tp.o[2] = o.z;
+            tp.dh[0] = dh.x; tp.dh[1] = dh.y; tp.dh[2] = dh.z;
+            tp.thr[0] = thr.x; tp.thr[1] = thr.y; tp.thr[2] = thr.z;
+            tp.len = len; tp.self_t = self_t; tp.prev = prev; tp.bounce = bounce;
+            tp.pixel = pixel; tp.sample = sample; tp.top_pixel = top_pixel;
+            slots[rank] = tp;
+        }
+        if (lane >= n_live && lane < PT_TAIL_PATHS) slots[lane].bounce = -1;
+    }
+
     // ---- the last sums to the frame ----
     if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
     if (c_valid) flush_bank(P, acc + 192 * parity, c_tx, c_ty, lane);
     unsigned int r = rays;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
-    if (lane == 0 && r) atomicAdd(P.ray_count, (unsigned long long)r);
+    if (lane == 0 && r) atomicAdd(ray_counter(P), (unsigned long long)r);
+}
+
+// The tail of a frame. When no job is left, a wave of k_render that holds at most PT_TAIL_PATHS paths (the long ones:
+// dozens of bounces between a sphere and the ground, or inside glass) hands them over and exits: finishing them there
+// would run the whole sequential scan for a few lanes at the latency of a lone wave (about 10 us per bounce), with most
+// of the chip idle. Here a path has a GROUP of 16 lanes (four paths per wave): the lanes of a group hold the same path
+// and share out the spheres (coop_scan). Same arithmetic per sphere, same hit rule, same philox blocks, integer sums:
+// the frame is bit for bit what k_render alone would produce. Slots are taken in a fixed order (group g takes g,
+// g + groups, ...): no counter, so nothing for thousands of groups to queue at.
+#define PT_TAIL_GROUP 16
+__global__ void __launch_bounds__(64) k_tail(const RenderParams P) {
+    constexpr int G = PT_TAIL_GROUP;
+    const int lane = threadIdx.x, sub = lane & (G - 1);
+    const int n_groups = int(gridDim.x) * (64 / G);
+    int next = int(blockIdx.x) * (64 / G) + lane / G;                     // the slot this group looks at next
+    const TailPath* slots = tail_slots(P);
+    unsigned int rays = 0;
+    bool active = false;
+    f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(0, 0, 0);
+    float len = 1.0f, self_t = 0.0f;
+    int prev = -1, bounce = 0;
+    uint32_t pixel = 0, sample = 0, top_pixel = 0;
+    for (;;) {
+        // a group without a path takes the next occupied slot of its sequence (the lanes of a group read the same words)
+        while (!active && next < P.n_tail_slots) {
+            const TailPath tp = slots[next];
+            next += n_groups;
+            if (tp.bounce < 0) continue;
+            o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
+            len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
+            pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
+            active = true;
+        }
+        if (!__any(active)) break;
+        if (active) {
+            if (sub == 0) ++rays;
+            float bt; int bi;
+            coop_scan<G>(P.scene, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
+                const f3 c = thr * sky(dh.y);
+                if (sub == 0) {
+                    const size_t plane = size_t(P.W) * size_t(P.H);
+                    unsigned long long* dst = P.accum_fx + top_pixel;
+                    const unsigned long long vx = to_fx(c.x), vy = to_fx(c.y), vz = to_fx(c.z);
+                    if (vx) atomicAdd(dst, vx);
+                    if (vy) atomicAdd(dst + plane, vy);
+                    if (vz) atomicAdd(dst + 2 * plane, vz);
+                }
+                active = false;
+            } else {
+                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
+                const MatRec mat = P.scene.mat[bi];
+                prev = bi;
+                ++bounce;
+                if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
+                    active = false;
+                } else {
+                    const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, P.key0, P.key1);
+                    f3 d, atten;
+                    const bool ok = shade(mat, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
+                    thr = thr * atten;                                               // Path Tracer.cpp:97
+                    o = h.p;
+                    dh = normalise(d, len);
+                    self_t = self_far_root(h.r, h.n, h.front, dh);
+                    active = ok;                                                     // Path Tracer.cpp:100 -> black
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) rays += __shfl_xor(rays, s);
+    if (lane == 0 && rays) atomicAdd(ray_counter(P), (unsigned long long)rays);
 }
 
 __global__ void k_resolve(unsigned long long* fx, float* out, size_t n_pixels, const unsigned long long* call_rays,
@@ -408,10 +534,12 @@ __global__ void k_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, u
 // Device memory the sample loop needs beyond its inputs and outputs: the planar u64[3][H][W] job sums and two
 // counters (rays of the call, next job). pt_render keeps them in buffers it allocates; pt_render_noalloc uses this
 // array instead, one copy per GPU, held until the process ends (PT_NOALLOC_MAX_PIXELS from include/pt_hip.h:
-// 49.8 MB). 32 words of counters, then the sums.
-#define PT_SCRATCH_COUNTER_WORDS 32
+// 1.5 MB + 49.8 MB). The counters and the queue between k_render<0> and k_tail (RenderParams::counters), then the sums.
+#define PT_SCRATCH_COUNTER_WORDS PT_COUNTER_WORDS
 #define PT_MAX_DEVICES 64
-static __device__ __align__(256) unsigned long long scratch[PT_SCRATCH_COUNTER_WORDS + 3 * size_t(PT_NOALLOC_MAX_PIXELS)];
+#define PT_SCRATCH_TAIL_ENTRIES (8192 * PT_TAIL_PATHS)          // 8 waves on each of the 1,024 SIMDs, PT_TAIL_PATHS paths each: 1.5 MB
+#define PT_SCRATCH_HEAD_WORDS (PT_SCRATCH_COUNTER_WORDS + PT_SCRATCH_TAIL_ENTRIES * (sizeof(TailPath) / 8))
+static __device__ __align__(256) unsigned long long scratch[PT_SCRATCH_HEAD_WORDS + 3 * size_t(PT_NOALLOC_MAX_PIXELS)];
 
 // =============================================================================================
 // Host side: the context and the C-ABI
@@ -454,12 +582,14 @@ struct pt_context {
     int acc_w = 0, acc_h = 0;
     unsigned char* d_rgb8 = nullptr;            // output stage (pt_quantise_rgb8): kept between frames, grows only
     size_t rgb8_cap = 0;
-    unsigned long long* d_counters = nullptr;   // [0] rays of the current call, [1] job counter, [2] rays since creation
+    unsigned long long* d_counters = nullptr;   // RenderParams::counters: 8 words ([3] = rays since creation) and the queue of k_tail
+    size_t tail_cap = 0;                        // capacity of that queue in entries
     int resident_waves = 0;                     // waves the device holds at once (persistent grid size)
     // kernel timing
     std::vector<hipEvent_t> ev;                 // pairs
     size_t ev_used = 0;
     int target_jobs = 262144;
+    int min_chunk = 4;                          // PT_MIN_CHUNK: fewest samples per pixel in a job
     int grid_factor_pct = 100;                  // PT_GRID_PCT: persistent grid as a percentage of the resident waves
 };
 
@@ -669,8 +799,21 @@ int pt_create(int device_index, pt_handle* out) {
     e = hipStreamCreate(&h->own_stream);
     if (e != hipSuccess) { delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     h->stream = h->own_stream;
-    e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 3 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, 3 * sizeof(unsigned long long));
+    {
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0);
+        if (e == hipSuccess) {
+            h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0);      // <2> needs no more
+            h->resident_waves_grid = std::max(1, per_cu) * prop.multiProcessorCount;
+        }
+        if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor: ") + hipGetErrorString(e)); }
+    }
+    if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
+    h->tail_cap = size_t(h->resident_waves) * size_t(std::max(100, h->grid_factor_pct)) / 100 * PT_TAIL_PATHS + 64;
+    const size_t counter_bytes = PT_COUNTER_WORDS * sizeof(unsigned long long) + h->tail_cap * sizeof(TailPath);
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), counter_bytes);
+    if (e == hipSuccess) e = hipMemset(h->d_counters, 0, counter_bytes);
     if (e != hipSuccess) { (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     // set-up that pt_render_noalloc must not do later: the address of this device's copy of `scratch`, and the
     // number of waves the device holds at once
@@ -686,17 +829,8 @@ int pt_create(int device_index, pt_handle* out) {
             g_scratch_ptr[device_index] = sp;
         }
     }
-    {
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0);
-        if (e != hipSuccess) { (void)hipFree(h->d_counters); (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor: ") + hipGetErrorString(e)); }
-        h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0);      // <2> needs no more
-        if (e != hipSuccess) { (void)hipFree(h->d_counters); (void)hipStreamDestroy(h->own_stream); delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipOccupancyMaxActiveBlocksPerMultiprocessor: ") + hipGetErrorString(e)); }
-        h->resident_waves_grid = std::max(1, per_cu) * prop.multiProcessorCount;
-    }
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
-    if (const char* gp = std::getenv("PT_GRID_PCT")) { int v = std::atoi(gp); if (v > 0) h->grid_factor_pct = v; }
+    if (const char* mc = std::getenv("PT_MIN_CHUNK")) { int v = std::atoi(mc); if (v > 0) h->min_chunk = v; }
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
     if (const char* gf = std::getenv("PT_GRID_FLAT")) h->grid_flat_ok = std::atoi(gf) != 0;
     if (const char* br = std::getenv("PT_GRID_BIG_RATIO")) { double v = std::atof(br); if (v >= 1 && v < 1e6) h->grid_big_ratio = v; }
@@ -881,9 +1015,10 @@ int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* a
 
 // The sample loop of one call, shared by pt_render and pt_render_noalloc: clears the two call counters, launches
 // k_render on the handle's stream (sums into fx, which must be zero), then k_resolve (fx -> out, fx back to zero).
-// Allocates nothing unless `timed` needs a new pair of events. counters: [0] rays of the call, [1] next job.
+// Allocates nothing unless `timed` needs a new pair of events. counters: RenderParams::counters (8 words, then the queue
+// of k_tail with room for tail_cap entries).
 static int render_core(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed, float* out,
-                       unsigned long long* fx, unsigned long long* counters, bool timed) {
+                       unsigned long long* fx, unsigned long long* counters, size_t tail_cap, bool timed) {
     const size_t n_elems = size_t(width) * height * 3;
     PT_HIP(h, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), h->stream));
     const int spp = spp_end - spp_begin;
@@ -896,7 +1031,8 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         long long want = (h->target_jobs + tiles - 1) / tiles;
         if (want < 1) want = 1;
         if (want > spp) want = spp;
-        if (want > (spp + 3) / 4) want = (spp + 3) / 4;     // at least 4 spp (256 items) per job
+        const int min_chunk = h->min_chunk;
+        if (want > (spp + min_chunk - 1) / min_chunk) want = (spp + min_chunk - 1) / min_chunk;     // at least min_chunk spp (x 64 items) per job
         P.spp_chunk = int((spp + want - 1) / want);
         P.n_chunks = (spp + P.spp_chunk - 1) / P.spp_chunk;
         const long long jobs = tiles * P.n_chunks;
@@ -912,12 +1048,15 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         if (use_grid && !h->grid_ready) return fail(h, PT_ERR_STATE, "pt_render: the grid has not been built");
         if (use_grid) P.grid = h->grid; else std::memset(&P.grid, 0, sizeof(P.grid));
         P.accum_fx = fx;
-        P.ray_count = counters;
-        P.job_counter = reinterpret_cast<unsigned int*>(counters + 1);
+        P.counters = counters;
+        P.n_tail_slots = 0;
         P.n_jobs = int(jobs);
         const bool flat = use_grid && h->grid_info[1] == 1 && h->grid_flat_ok;       // one layer of cells: the walk without a y axis
         const int resident = use_grid ? h->resident_waves_grid : h->resident_waves;   // from pt_create
-        const long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
+        long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
+        if (!use_grid) grid = std::min<long long>(grid, (long long)(tail_cap / PT_TAIL_PATHS));      // every wave may queue PT_TAIL_PATHS paths
+        // a wave's first job is its own number: the counter starts behind them
+        PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 1), int(grid < 1 ? 1 : grid), 1, h->stream));
         timed = timed && h->ev_used + 2 <= 8192;
         if (timed && h->ev.size() < h->ev_used + 2) {
             hipEvent_t a, b;
@@ -927,14 +1066,20 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
         if (flat) hipLaunchKernelGGL(k_render<2>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
         else if (use_grid) hipLaunchKernelGGL(k_render<1>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
-        else hipLaunchKernelGGL(k_render<0>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        else {
+            hipLaunchKernelGGL(k_render<0>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+            PT_HIP(h, hipGetLastError());
+            // the long paths the waves of k_render were left with (counted into the kernel time)
+            P.n_tail_slots = int((grid < 1 ? 1 : grid) * PT_TAIL_PATHS);
+            hipLaunchKernelGGL(k_tail, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+        }
         PT_HIP(h, hipGetLastError());
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
     }
     {
         const size_t n_pixels = n_elems / 3;
         const unsigned blocks = unsigned(std::min<size_t>((n_pixels + 255) / 256, 256 * 16));
-        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, fx, out, n_pixels, counters, h->d_counters + 2);
+        hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(256), 0, h->stream, fx, out, n_pixels, counters, h->d_counters + 3);
         PT_HIP(h, hipGetLastError());
     }
     return 0;
@@ -969,7 +1114,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         PT_HIP(h, hipMemsetAsync(h->d_fx, 0, n_elems * sizeof(unsigned long long), h->stream));
         h->fx_elems = n_elems;
     }
-    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, out, h->d_fx, h->d_counters, true)) return rc;
+    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, out, h->d_fx, h->d_counters, h->tail_cap, true)) return rc;
 #ifdef PT_STATS
     {
         unsigned long long st[8];
@@ -1007,9 +1152,9 @@ int pt_render_noalloc(pt_handle h, int width, int height, int spp_begin, int spp
     // The array keeps whatever the last call on this GPU left (k_resolve leaves the sums it read at zero, but a call
     // that failed half-way would not): clear the part this call uses.
     const size_t n_elems = size_t(width) * height * 3;
-    unsigned long long* fx = sp + PT_SCRATCH_COUNTER_WORDS;
+    unsigned long long* fx = sp + PT_SCRATCH_HEAD_WORDS;
     PT_HIP(h, hipMemsetAsync(fx, 0, n_elems * sizeof(unsigned long long), h->stream));
-    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, accum_rgb_f32, fx, sp, false)) return rc;
+    if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, accum_rgb_f32, fx, sp, PT_SCRATCH_TAIL_ENTRIES, false)) return rc;
     if (ray_count_dev) PT_HIP(h, hipMemcpyAsync(ray_count_dev, sp, sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
@@ -1018,7 +1163,7 @@ int pt_ray_count(pt_handle h, uint64_t* out) {
     if (!h || !out) return PT_ERR_INVALID;
     PT_HIP(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    PT_HIP(h, hipMemcpyAsync(&v, h->d_counters + 2, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    PT_HIP(h, hipMemcpyAsync(&v, h->d_counters + 3, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     *out = v;
     return 0;
