@@ -221,10 +221,10 @@ def extras(dev, host, accum, W, H, spp, depth, scene, cam):
     dev.set_scene(small)
     dev.set_camera(host.camera_setup(aspect=400 / 225))
     sbuf = torch.zeros((225, 400, 3), dtype=torch.float32, device="cuda")
-    kernel_ms(2, 100, 400, 225, sbuf)
+    kernel_ms(20, 100, 400, 225, sbuf)          # a 1.5 ms kernel: the clocks need some tens of launches to settle
     r0 = dev.ray_count()
-    ms_small = kernel_ms(1, 100, 400, 225, sbuf)
-    rays_small = dev.ray_count() - r0
+    ms_small = kernel_ms(20, 100, 400, 225, sbuf)
+    rays_small = (dev.ray_count() - r0) / 20
     n_small = len(small["kind"])
     res["configs0_scene_on_gpu_400x225_100spp"] = {
         "spheres": n_small, "kernel_ms": ms_small, "Msamples_per_s": 400 * 225 * 100 / ms_small / 1e3,

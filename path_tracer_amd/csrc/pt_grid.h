@@ -44,7 +44,6 @@ struct GridWalk {
     float tmx, tmy, tmz;          // distance along the ray to the next cell wall on each axis
     float tdx, tdy, tdz;          // distance between walls
     float t_out;                  // far side of the box
-    float tmin;
     float best_t;                 // closest hit so far (starts as the big list's)
     int best_i;
     int ci, sx, sy, sz;           // cell index and its step on each axis
@@ -61,7 +60,7 @@ PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, floa
     float best_t; int best_i;
     scan_spheres(G.big, o, dh, tmin, prev_local, self_t, best_t, best_i);
     if (best_i >= 0) best_i = G.big_ids[best_i];
-    w.best_t = best_t; w.best_i = best_i; w.tmin = tmin;
+    w.best_t = best_t; w.best_i = best_i;
     w.prev_in_grid = (prev >= 0) & (prev_local < 0);
 
     // The shape of the grid comes through the scalar cache here, where it is used (an opaque copy of the pointer
@@ -109,8 +108,9 @@ PT_DEV void grid_begin(const GridDev& G, f3 o, f3 dh, float tmin, int prev, floa
 // Every pass consumes an entry or moves one cell on: at most nx + ny + nz + 3 + entries passes per walk.
 // FLAT: the grid is one layer of cells (ny = 1, the reference's scenes: spheres on the ground). The walk then
 // never moves along y; where the ray leaves the layer is the far side of the box, t_out.
+// tmin: the ray's, as given to grid_begin (the caller recomputes it from the ray's length rather than keep it in a register).
 template <bool FLAT>
-PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
+PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, float tmin, int prev, GridWalk& w) {
     const bool has = w.k < w.kend;
     const float4 s = G.items[w.k];                    // one entry past the last is allocated: k == kend is readable
     const int id = G.ids[w.k];
@@ -150,9 +150,9 @@ PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
     const float T = __builtin_fmaf(-perp.z, perp.z, __builtin_fmaf(-perp.y, perp.y, __builtin_fmaf(-perp.x, perp.x, s.w)));   // :9-10
     const float sq = fast_sqrt(T);                                        // NaN for T < 0: t is NaN, the compares below false
     const float t1 = b - sq, t2 = b + sq;
-    const float t = (t1 >= w.tmin) ? t1 : t2;                             // :17-19
+    const float t = (t1 >= tmin) ? t1 : t2;                               // :17-19
     const bool closer = (t < w.best_t) | ((t == w.best_t) & (id > w.best_i));   // HittableList.cpp:28-31: later index wins ties
-    const bool ok = has & (id != prev) & (t >= w.tmin) & closer;
+    const bool ok = has & (id != prev) & (t >= tmin) & closer;
     w.best_t = ok ? t : w.best_t;
     w.best_i = ok ? id : w.best_i;
     w.k = has ? w.k + 1 : r0;
@@ -162,8 +162,8 @@ PT_DEV void grid_pass(const GridDev& G, f3 o, f3 dh, int prev, GridWalk& w) {
 
 // The answer of a finished walk. The sphere the ray starts on, when it lives in the grid: its near root is the
 // start point, its far root (self_t) counts when the ray heads into the sphere (see scan_spheres).
-PT_DEV void grid_end(const GridWalk& w, int prev, float self_t, float& best_t, int& best_i) {
-    const bool ok = w.prev_in_grid & (self_t >= w.tmin) & (self_t <= w.best_t);
+PT_DEV void grid_end(const GridWalk& w, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+    const bool ok = w.prev_in_grid & (self_t >= tmin) & (self_t <= w.best_t);
     best_t = ok ? self_t : w.best_t;
     best_i = ok ? prev : w.best_i;
 }
@@ -181,9 +181,9 @@ PT_DEV void scan_grid(const GridDev& G, f3 o, f3 dh, float tmin, int prev, float
             if (threadIdx.x == 0) { atomicAdd(&g_stats[5], 1ull); atomicAdd(&g_stats[6], (unsigned long long)__popcll(lm)); atomicAdd(&g_stats[7], (unsigned long long)__popcll(hm)); }
         }
 #endif
-        if (w.live) grid_pass<FLAT>(G, o, dh, prev, w);
+        if (w.live) grid_pass<FLAT>(G, o, dh, tmin, prev, w);
     }
-    grid_end(w, prev, self_t, best_t, best_i);
+    grid_end(w, tmin, prev, self_t, best_t, best_i);
 }
 
 }   // namespace ptd

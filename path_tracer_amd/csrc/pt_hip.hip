@@ -97,6 +97,10 @@ __device__ unsigned long long g_stats[8];
 
 // Adds one LDS bank of job sums to the frame and clears it. Lane l owns pixel slot l of the tile.
 PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, int ty, int lane) {
+    // Opaque copy: everything derived from the lane number below (the LDS offset, the pixel) is then computed here, at
+    // a job switch, instead of being kept in registers through the whole loop (the grid kernels have none to spare
+    // and would spill them).
+    asm volatile("" : "+v"(lane));
     const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
     if (px < P.W && py < P.H) {
         // planar sums: the 8 lanes of a tile row add to 64 contiguous bytes
@@ -112,7 +116,9 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #endif
         }
     }
-    bank[lane * 3 + 0] = 0; bank[lane * 3 + 1] = 0; bank[lane * 3 + 2] = 0;
+    unsigned long long zero = 0;
+    asm volatile("" : "+v"(zero));
+    bank[lane * 3 + 0] = zero; bank[lane * 3 + 1] = zero; bank[lane * 3 + 2] = zero;
 }
 
 // Persistent waves. Each wave pulls jobs (8x8 tile x sample chunk) from a global counter and hands
@@ -143,7 +149,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 
     // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining
     int parity = 0;
-    int c_tx = 0, c_ty = 0, c_s0 = 0, c_total = 0, c_next = 0;
+    int c_tx = 0, c_ty = 0, c_s0 = 0, c_vh = 8, c_total = 0, c_next = 0;
     int o_tx = 0, o_ty = 0;
     bool c_valid = false, o_valid = false, no_more_jobs = false;
 
@@ -154,12 +160,13 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(1, 1, 1);
     float len = 1.0f;
     float self_t = 0.0f;
-    int slot = 0, bounce = 0, prev = -1, lbank = 0;
+    int bounce = 0, prev = -1;
+    int sb = 0;   // where the path's radiance goes: pixel slot of the tile (0..63) + 64 x LDS bank (0, 1), or 128: straight to the frame
     uint32_t pixel = 0, sample = 0, top_pixel = 0;   // pixel: counted from the bottom row like the reference's j; top_pixel: index into the frame
 
     // MODE 1 (grid of several layers) and 2 (one layer of cells) only: the walk through the grid of this lane's ray, and whether its answer waits to be used
     GridWalk gw;
-    gw.tmx = gw.tmy = gw.tmz = gw.tdx = gw.tdy = gw.tdz = gw.t_out = gw.tmin = gw.best_t = 0.0f;
+    gw.tmx = gw.tmy = gw.tmz = gw.tdx = gw.tdy = gw.tdz = gw.t_out = gw.best_t = 0.0f;
     gw.best_i = -1; gw.ci = gw.sx = gw.sy = gw.sz = 0; gw.k = gw.kend = 0u; gw.prev_in_grid = false; gw.live = false;
     bool walking = false, pending = false;
 
@@ -187,7 +194,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                   PT_STAT_ADD(5, 1); PT_STAT_ADD(6, nw); PT_STAT_ADD(7, nh); }
 #endif
                 if (walking) {
-                    grid_pass<MODE == 2>(P.grid, o, dh, prev, gw);
+                    grid_pass<MODE == 2>(P.grid, o, dh, 0.001f * len, prev, gw);
                     if (!gw.live) { walking = false; pending = true; }
                 }
             }
@@ -197,11 +204,11 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             ++rays;
             float bt; int bi;
             if constexpr (MODE == 0) scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            else { grid_end(gw, prev, self_t, bt, bi); pending = false; }
+            else { grid_end(gw, 0.001f * len, prev, self_t, bt, bi); pending = false; }
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
-                if (lbank < 2) {
-                    unsigned long long* a = acc + 192 * lbank + slot * 3;
+                if (sb < 128) {
+                    unsigned long long* a = acc + sb * 3;                            // bank b starts at word 192 b = 3 x 64 b
                     atomicAdd(a + 0, to_fx(c.x));
                     atomicAdd(a + 1, to_fx(c.y));
                     atomicAdd(a + 2, to_fx(c.z));
@@ -226,18 +233,24 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
         }
 
         // ---- hand new items to the lanes whose path has ended (regeneration) ----
-        bool need = !active;
+        // Straight-line: the lanes that need an item are ranked; the first `rem` of them take what the current job has
+        // left, and if that is not enough the wave fetches the next job NOW and the others draw from it in the same
+        // pass. A lane left without an item (the new job is a small one of the bottom edge, or the item lies in the
+        // part of a tile that sticks out on the right) simply asks again in the next iteration.
         bool fresh = false;
         int px = 0, j = 0;
-        while (__any(need)) {
-            if (c_next >= c_total) {                         // wave-uniform: the current job is handed out
-                if (no_more_jobs) break;
+        const unsigned long long need_mask = __ballot(!active);
+        if (need_mask != 0ull && !(no_more_jobs && c_next >= c_total)) {               // wave-uniform
+            const int n_need = __popcll(need_mask);
+            const int rem = c_total - c_next;                                        // items left in the current job
+            int n_tx = 0, n_ty = 0, n_s0 = 0, n_vh = 8, n_total = 0;
+            bool have_new = false;
+            if (rem < n_need && !no_more_jobs) {
                 // The other bank may still have paths in flight (a path of 30 bounces outlives the whole next job).
                 // Waiting for them would idle every finished lane; instead its sums go to the frame now and the
                 // stragglers add their result straight to the frame when they end (integer sums: any order).
-                if (active && lbank != parity) lbank = 2;
+                if (active && (sb >> 6) != parity) sb = 128;
                 if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
-                // the index asked for when the previous job began (the round trip to the counter takes microseconds)
                 // A wave's first job is its own number (the launch has at most as many waves as jobs); the counter hands
                 // out the rest. Thousands of waves asking one address at the same moment would queue for ~0.1 ms.
                 int job = int(blockIdx.x);
@@ -245,37 +258,51 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                     if (lane == 0) job = int(atomicAdd(job_counter(P), 1u));
                     job = __builtin_amdgcn_readfirstlane(job);
                 }
-                if (job >= P.n_jobs) { no_more_jobs = true; break; }
-                o_tx = c_tx; o_ty = c_ty; o_valid = c_valid;
-                parity ^= 1;
-                const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
-                c_ty = tile / P.tiles_x; c_tx = tile - c_ty * P.tiles_x;
-                c_s0 = P.spp_begin + chunk * P.spp_chunk;
-                c_total = 64 * (min(c_s0 + P.spp_chunk, P.spp_end) - c_s0);
-                c_next = 0;
-                c_valid = true;
-                continue;
+                if (job >= P.n_jobs) {
+                    no_more_jobs = true;
+                } else {
+                    have_new = true;
+                    const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
+                    n_ty = tile / P.tiles_x; n_tx = tile - n_ty * P.tiles_x;
+                    n_s0 = P.spp_begin + chunk * P.spp_chunk;
+                    n_vh = min(8, P.H - 8 * n_ty);                                   // rows of the tile inside the image
+                    n_total = 8 * n_vh * (min(n_s0 + P.spp_chunk, P.spp_end) - n_s0);
+                }
             }
-            const unsigned long long m = __ballot(need);
-            const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0));
-            const int k = c_next + rank;
-            c_next += __popcll(m);
-            if (need && k < c_total) {
-                const int s = k & 63;
-                const int x = c_tx * 8 + (s & 7), py = c_ty * 8 + (s >> 3);          // py from the top
-                if (x < P.W && py < P.H && P.max_depth > 0) {                        // Path Tracer.cpp:86
-                    slot = s;
+            const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need_mask), 0));
+            const bool from_new = rank >= rem;
+            const int k = from_new ? rank - rem : c_next + rank;                     // item number within its job
+            if (!active && (!from_new || (have_new && k < n_total))) {               // (a bottom-edge tile's job may hold fewer than 64 items)
+                const int tx = from_new ? n_tx : c_tx, ty = from_new ? n_ty : c_ty, s0 = from_new ? n_s0 : c_s0;
+                // item k = (sample, row, column) with the column fastest, over the rows of the tile that exist
+                int row = (k >> 3) & 7, smp = k >> 6;
+                if (c_vh != 8 || n_vh != 8) {                                        // wave-uniform: a tile of the bottom edge
+                    const int vh = from_new ? n_vh : c_vh;
+                    const int t = k >> 3;
+                    smp = int((float(t) + 0.5f) * __builtin_amdgcn_rcpf(float(vh)));  // t / vh for vh <= 8, t < 2^20: the quotient is at least 1/16 from an integer
+                    row = t - smp * vh;
+                }
+                const int x = tx * 8 + (k & 7), py = ty * 8 + row;                   // py from the top
+                if (x < P.W) {                                                       // (max_depth >= 1: the host launches nothing for 0)
+                    sb = row * 8 + (k & 7) + 64 * (from_new ? (parity ^ 1) : parity);
                     px = x;
                     j = P.H - 1 - py;                                                // Path Tracer.cpp:298
                     pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
-                    sample = uint32_t(c_s0 + (k >> 6));
+                    sample = uint32_t(s0 + smp);
                     bounce = 0;
                     prev = -1;
-                    lbank = parity;
                     top_pixel = uint32_t(py) * uint32_t(P.W) + uint32_t(px);
                     fresh = active = true;
-                    need = false;
                 }
+            }
+            if (have_new) {
+                o_tx = c_tx; o_ty = c_ty; o_valid = c_valid;
+                parity ^= 1;
+                c_tx = n_tx; c_ty = n_ty; c_s0 = n_s0; c_vh = n_vh; c_total = n_total;
+                c_next = min(n_need - max(rem, 0), n_total);
+                c_valid = true;
+            } else {
+                c_next += min(n_need, max(rem, 0));
             }
         }
         if (!__any(active)) {
@@ -1022,7 +1049,7 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
     const size_t n_elems = size_t(width) * height * 3;
     PT_HIP(h, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), h->stream));
     const int spp = spp_end - spp_begin;
-    if (spp > 0) {
+    if (spp > 0 && max_depth > 0) {          // depth 0: calcColour returns black before it traces anything (Path Tracer.cpp:86)
         RenderParams P;
         P.W = width; P.H = height;
         P.spp_begin = spp_begin; P.spp_end = spp_end;

@@ -84,18 +84,23 @@ def test_product_never_touches_the_oracle():
                     assert "oracle" not in text.lower(), os.path.join(dirpath, f)
 
 
-def test_hand_written_scalar_loads_are_not_touched_in_flight(tmp_path):
-    """pt_device.h issues s_load_dwordx16 from inline asm and waits for it in a separate statement. Compile to
-    assembly and check that nothing between a load and its wait reads or writes the registers being loaded."""
+def test_compiled_kernels_pass_the_static_checks():
+    """`make check` (part of `make all`): pt_device.h issues s_load_dwordx16 from inline asm and waits for it in a separate
+    statement, so nothing between a load and its wait may read or write the registers being loaded (tools/check_sload.py,
+    default flags and the PT_STATS build); and k_render<0|1|2> and k_tail must use no scratch memory, spill no vector
+    register and keep their occupancy (tools/check_resources.py)."""
     import shutil
     import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this machine")
-    out = str(tmp_path / "pt_hip.s")
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out,
-                           os.path.join(ROOT, "path_tracer_amd", "csrc", "pt_hip.hip")], stderr=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-s", "-C", ROOT, "check", "HIPCC=" + hipcc], stdout=subprocess.DEVNULL)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_resources
     import check_sload
-    n, problems = check_sload.check(out)
+    n, problems = check_sload.check(os.path.join(ROOT, "tools", "build", "pt_hip.s"))
+    assert n >= 4 and not problems, problems
+    n, problems = check_sload.check(os.path.join(ROOT, "tools", "build", "pt_hip_stats.s"))
+    assert n >= 4 and not problems, problems
+    n, problems = check_resources.check(os.path.join(ROOT, "tools", "build", "pt_hip.resources.txt"))
     assert n >= 4 and not problems, problems

@@ -12,4 +12,8 @@ for round in 1 2; do for lib in "$@"; do for mc in ${CHUNKS:-4}; do
   echo "== $lib configs3"
   PT_HIP_LIB=$PWD/tools/build/$lib DIFFUSE=0.1 METAL=0.5 DEPTH=100 REPS=5 timeout -k 10 120 python3 tools/perf_run.py | tail -1 | sed 's/kernel ms.*\]//' || exit 1
   fi
+  if [ -n "$GRID" ]; then
+  echo "== $lib configs1 grid"
+  ACCEL=1 PT_HIP_LIB=$PWD/tools/build/$lib REPS=5 timeout -k 10 120 python3 tools/perf_run.py | tail -2 | sed 's/kernel ms.*\]//' || exit 1
+  fi
 done; done
