@@ -242,8 +242,9 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
 // scan_quad and tier2 operation for operation, and the rule "smallest t, then largest index" does not depend on the
 // order of the comparisons, so the answer is bit for bit the one scan_spheres gives. Used by k_tail for the long
 // paths left at the end of a frame, where latency counts and most of the chip is idle.
-template <int G>
-PT_DEV void coop_scan(const SceneDev& sc, int sub, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+// `scan` = the scan records (SceneDev::scan) in global memory or a copy of them in LDS, n_pad as in SceneDev.
+template <int G, class RecPtr>
+PT_DEV void coop_scan(RecPtr scan, int n_pad, int sub, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
     const float od = dot(o, dh);
     const f3 p = fma3(dh, -od, o);
     const float ne = -dot(p, dh);
@@ -254,9 +255,9 @@ PT_DEV void coop_scan(const SceneDev& sc, int sub, f3 o, f3 dh, float tmin, int 
     self_t += shift;
     best_t = __builtin_inff();
     best_i = -1;
-    const int n_quads = sc.n_pad >> 2;
+    const int n_quads = n_pad >> 2;
     for (int q = sub; q < n_quads; q += G) {
-        const float4* rec = reinterpret_cast<const float4*>(sc.scan + 16 * size_t(q));
+        const auto* rec = reinterpret_cast<const float4*>(scan + 16 * size_t(q));
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
         const float R[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
 #pragma unroll
@@ -329,8 +330,7 @@ struct HitRec {
     double t_unit;
     double px, py, pz, nx, ny, nz;   // the same point and normal before rounding to fp32
 };
-PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, double tmin) {
-    const GeomRec g = sc.geom[idx];
+PT_DEV HitRec finish_hit(const GeomRec& g, bool self, f3 o, f3 dh, double tmin) {
     const double ox = o.x, oy = o.y, oz = o.z, dx = dh.x, dy = dh.y, dz = dh.z;
     const double ocx = ox - g.cx, ocy = oy - g.cy, ocz = oz - g.cz;            // Sphere.cpp:6
     const double a = dx * dx + dy * dy + dz * dz;                                // :7 (1 +- 2e-7)
@@ -353,6 +353,9 @@ PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, do
     h.p = mk3(float(h.px), float(h.py), float(h.pz));
     h.n = mk3(float(h.nx), float(h.ny), float(h.nz));
     return h;
+}
+PT_DEV HitRec finish_hit(const SceneDev& sc, int idx, bool self, f3 o, f3 dh, double tmin) {
+    return finish_hit(sc.geom[idx], self, o, dh, tmin);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -390,12 +390,32 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 // and share out the spheres (coop_scan). Same arithmetic per sphere, same hit rule, same philox blocks, integer sums:
 // the frame is bit for bit what k_render alone would produce. Slots are taken in a fixed order (group g takes g,
 // g + groups, ...): no counter, so nothing for thousands of groups to queue at.
+#ifndef PT_TAIL_GROUP
 #define PT_TAIL_GROUP 16
-__global__ void __launch_bounds__(64) k_tail(const RenderParams P) {
+#endif
+#define PT_TAIL_LDS_MAX 65536        // a workgroup's LDS limit: the scene copies of k_tail<true> must fit
+// LDS: the scan records, the double-precision spheres and the materials are first copied into LDS (scenes up to a
+// few hundred spheres: 97 bytes per sphere), so that a bounce makes no trip to L2: the tail is pure latency.
+template <bool LDS>
+__global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
-    const int lane = threadIdx.x, sub = lane & (G - 1);
-    const int n_groups = int(gridDim.x) * (64 / G);
-    int next = int(blockIdx.x) * (64 / G) + lane / G;                     // the slot this group looks at next
+    extern __shared__ __align__(16) unsigned char tail_lds[];
+    const int tid = threadIdx.x, sub = tid & (G - 1);
+    const int n_rec_floats = (P.scene.n_pad + 8) * 4;
+    float* l_scan = reinterpret_cast<float*>(tail_lds);
+    GeomRec* l_geom = reinterpret_cast<GeomRec*>(tail_lds + size_t(n_rec_floats) * 4);
+    MatRec* l_mat = reinterpret_cast<MatRec*>(reinterpret_cast<unsigned char*>(l_geom) + size_t(P.scene.n) * sizeof(GeomRec));
+    if constexpr (LDS) {
+        const float4* gs = reinterpret_cast<const float4*>(P.scene.scan);
+        for (int i = tid; i < n_rec_floats / 4; i += 256) reinterpret_cast<float4*>(l_scan)[i] = gs[i];
+        const double2* gg = reinterpret_cast<const double2*>(P.scene.geom);
+        for (int i = tid; i < P.scene.n * 3; i += 256) reinterpret_cast<double2*>(l_geom)[i] = gg[i];
+        const float4* gm = reinterpret_cast<const float4*>(P.scene.mat);
+        for (int i = tid; i < P.scene.n * 2; i += 256) reinterpret_cast<float4*>(l_mat)[i] = gm[i];
+        __syncthreads();
+    }
+    const int n_groups = int(gridDim.x) * (256 / G);
+    int next = int(blockIdx.x) * (256 / G) + tid / G;                     // the slot this group looks at next
     const TailPath* slots = tail_slots(P);
     unsigned int rays = 0;
     bool active = false;
@@ -414,11 +434,12 @@ __global__ void __launch_bounds__(64) k_tail(const RenderParams P) {
             pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
             active = true;
         }
-        if (!__any(active)) break;
+        if (!__any(active)) break;                                        // (waves of a workgroup leave independently: no barrier below)
         if (active) {
             if (sub == 0) ++rays;
             float bt; int bi;
-            coop_scan<G>(P.scene, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if constexpr (LDS) coop_scan<G>(l_scan, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            else coop_scan<G>(P.scene.scan, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 if (sub == 0) {
@@ -431,8 +452,9 @@ __global__ void __launch_bounds__(64) k_tail(const RenderParams P) {
                 }
                 active = false;
             } else {
-                const HitRec h = finish_hit(P.scene, bi, bi == prev, o, dh, 0.001 * double(len));
-                const MatRec mat = P.scene.mat[bi];
+                const GeomRec g = LDS ? l_geom[bi] : P.scene.geom[bi];
+                const MatRec mat = LDS ? l_mat[bi] : P.scene.mat[bi];
+                const HitRec h = finish_hit(g, bi == prev, o, dh, 0.001 * double(len));
                 prev = bi;
                 ++bounce;
                 if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
@@ -452,7 +474,7 @@ __global__ void __launch_bounds__(64) k_tail(const RenderParams P) {
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) rays += __shfl_xor(rays, s);
-    if (lane == 0 && rays) atomicAdd(ray_counter(P), (unsigned long long)rays);
+    if ((tid & 63) == 0 && rays) atomicAdd(ray_counter(P), (unsigned long long)rays);
 }
 
 __global__ void k_resolve(unsigned long long* fx, float* out, size_t n_pixels, const unsigned long long* call_rays,
@@ -612,6 +634,7 @@ struct pt_context {
     unsigned long long* d_counters = nullptr;   // RenderParams::counters: 8 words ([3] = rays since creation) and the queue of k_tail
     size_t tail_cap = 0;                        // capacity of that queue in entries
     int resident_waves = 0;                     // waves the device holds at once (persistent grid size)
+    int n_cus = 256;
     // kernel timing
     std::vector<hipEvent_t> ev;                 // pairs
     size_t ev_used = 0;
@@ -831,6 +854,7 @@ int pt_create(int device_index, pt_handle* out) {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<0>, 64, 0);
         if (e == hipSuccess) {
             h->resident_waves = std::max(1, per_cu) * prop.multiProcessorCount;
+            h->n_cus = prop.multiProcessorCount;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render<1>, 64, 0);      // <2> needs no more
             h->resident_waves_grid = std::max(1, per_cu) * prop.multiProcessorCount;
         }
@@ -1098,7 +1122,12 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
             PT_HIP(h, hipGetLastError());
             // the long paths the waves of k_render were left with (counted into the kernel time)
             P.n_tail_slots = int((grid < 1 ? 1 : grid) * PT_TAIL_PATHS);
-            hipLaunchKernelGGL(k_tail, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
+            const size_t lds = size_t(P.scene.n_pad + 8) * 16 + size_t(P.scene.n) * (sizeof(GeomRec) + sizeof(MatRec));
+            const unsigned tail_blocks = unsigned((P.n_tail_slots + 256 / PT_TAIL_GROUP - 1) / (256 / PT_TAIL_GROUP));   // one slot per group
+            // with the scene in LDS a compute unit holds 160 KB / lds workgroups at a time: no more than fill the chip once
+            const unsigned lds_blocks = std::min<unsigned>(tail_blocks, unsigned(h->n_cus) * unsigned(std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1))));
+            if (lds <= PT_TAIL_LDS_MAX) hipLaunchKernelGGL(k_tail<true>, dim3(lds_blocks), dim3(256), lds, h->stream, P);
+            else hipLaunchKernelGGL(k_tail<false>, dim3(tail_blocks), dim3(256), 0, h->stream, P);
         }
         PT_HIP(h, hipGetLastError());
         if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }

@@ -13,7 +13,7 @@ WANT = {                                  # kernel (mangled prefix) -> fewest wa
     "_Z8k_renderILi0E": 6,
     "_Z8k_renderILi1E": 5,
     "_Z8k_renderILi2E": 5,
-    "_Z6k_tail": 5,
+    "_Z6k_tailILb": 4,
 }
 
 
