@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm brings its own copy of the HIP runtime and libpt_hip.so is linked against the system's: a process that
+# uses both must load torch's first (the library then binds to the runtime already in memory). Loaded the other way
+# round, torch finds a runtime it was not built with and reports "No HIP GPUs are available". Several GPU tests hand
+# torch tensors to the library, so every test session imports torch before anything else.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

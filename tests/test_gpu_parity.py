@@ -3,8 +3,11 @@ against the committed fixtures and against the hand-derived known answers.
 
 Tolerances (BASELINE.json north_star):
   * scene buffers: bit-exact (CPU tests: test_host.py);
-  * per-ray t, point, normal, scatter direction under injected numbers: 1e-4 relative to the double
-    path (REL below; measured errors are ~1e-6);
+  * per-ray t, point, normal, scatter direction under injected numbers: north_star's bar is 1e-4 relative to the
+    double path (REL below). Every assert here is tighter: at most 2x what the device measurably achieves on that
+    input (each test prints its maxima as "[measured] ..."; DESIGN.md section 5 lists them). The kernels are
+    deterministic, so the measured numbers repeat exactly on gfx950; a compiler change that moves them needs the
+    bars re-measured, which is the point;
   * frame under identical philox numbers: per-pixel agreement up to the few paths whose discrete
     decisions flip in fp32; frame under different numbers: per-pixel RMSE within the expected
     sigma at matched spp and mean luminance within 0.5 %.
@@ -83,7 +86,8 @@ def test_gen_ray_T5(dev, orc, scene250):
     use(dev, sc, cam)
     g = np.load(os.path.join(GOLDEN, "t5_gen_ray.npz"))
     o, d = dev.gen_ray(int(g["W"]), int(g["H"]), g["pi"], g["pj"], g["u1"], g["u2"], g["diskx"], g["disky"])
-    assert vec_rel_err(o, g["o"]).max() < REL and vec_rel_err(d, g["d"]).max() < REL
+    print("[measured] T5 ray generation fixture: o %.2e d %.2e" % (vec_rel_err(o, g["o"]).max(), vec_rel_err(d, g["d"]).max()))
+    assert vec_rel_err(o, g["o"]).max() < 1.2e-7 and vec_rel_err(d, g["d"]).max() < 3.9e-7
     # a non-default camera and a 4K frame, against the live oracle
     kw = dict(pos=(3, 5, 9), look=(1, 0.5, 0), up=(0, 1, 0), aspect=1.7777777777, focal=1.5, fov=40.0, aperture=0.3)
     cam2 = orc.camera_setup(**kw)
@@ -95,18 +99,30 @@ def test_gen_ray_T5(dev, orc, scene250):
     dx, dy = f32(rng.uniform(-0.7, 0.7, n)), f32(rng.uniform(-0.7, 0.7, n))
     o, d = dev.gen_ray(3840, 2160, pi, pj, u1, u2, dx, dy)
     oo, od = orc.gen_ray(cam2, 3840, 2160, pi, pj, u1, u2, dx, dy)
-    assert vec_rel_err(o, oo).max() < REL and vec_rel_err(d, od).max() < REL
+    print("[measured] T5 ray generation, 4K frame: o %.2e d %.2e" % (vec_rel_err(o, oo).max(), vec_rel_err(d, od).max()))
+    assert vec_rel_err(o, oo).max() < 1e-7 and vec_rel_err(d, od).max() < 3e-7
     dev.set_camera(cam)
 
 
-def check_scan(g, r, allow_mismatch=0):
+FAR_N_TOL = 6.2e-4  # normals of hits seen from 300 units away (measured 3.1e-4): see test_scan_rays_from_far_away
+MEASURED = {}       # name -> measured maxima, printed by each test (pytest -s shows them; DESIGN.md section 5 records them)
+
+
+def check_scan(g, r, allow_mismatch=0, name=None, t_tol=REL, p_tol=REL, n_tol=REL):
+    """Device scan against the double path. The bars are at most 2x what the device measurably achieves (the
+    per-test numbers are in DESIGN.md section 5), never looser than north_star's 1e-4."""
     mism = g["idx"] != r["idx"]
-    assert mism.sum() <= allow_mismatch, "index mismatches: %d" % mism.sum()
     hit = ~mism & (r["idx"] >= 0)
     assert hit.sum() > 0
-    assert (np.abs(g["t"][hit] - r["t"][hit]) / r["t"][hit]).max() < REL
-    assert vec_rel_err(g["p"][hit], r["p"][hit]).max() < REL
-    assert np.abs(g["n"][hit] - r["n"][hit]).max() < REL          # unit vectors: absolute = relative
+    m = dict(mismatches=int(mism.sum()), n=len(mism),
+             t=float((np.abs(g["t"][hit] - r["t"][hit]) / r["t"][hit]).max()),
+             p=float(vec_rel_err(g["p"][hit], r["p"][hit]).max()),
+             nrm=float(np.abs(g["n"][hit] - r["n"][hit]).max()))          # unit vectors: absolute = relative
+    if name:
+        MEASURED[name] = m
+        print("[measured] %s: %s" % (name, m))
+    assert m["mismatches"] <= allow_mismatch, "index mismatches: %d" % m["mismatches"]
+    assert m["t"] < t_tol and m["p"] < p_tol and m["nrm"] < n_tol, m
     assert np.array_equal(g["front"][hit], r["front"][hit])
     return hit
 
@@ -117,7 +133,7 @@ def test_scan_T3_fixture(dev, scene250):
     g = np.load(os.path.join(GOLDEN, "t3_scan.npz"))
     r = {k: g["r_" + k] for k in ("t", "idx", "p", "n", "front")}
     out = dev.scan(g["o"], g["d"])
-    hit = check_scan(out, r, allow_mismatch=1)
+    hit = check_scan(out, r, allow_mismatch=0, name="T3 fixture (255 spheres, 4096 rays)", t_tol=1.5e-6, p_tol=1.2e-6, n_tol=6e-6)
     assert (r["idx"][hit] == 1).sum() > 100          # plenty of ground hits (r = 1000), many of them grazing
 
 
@@ -134,21 +150,23 @@ def test_scan_T3_live_500_spheres(dev, orc):
     d = rng.normal(size=(n, 3))
     d[:, 1] = -np.abs(d[:, 1])
     d = f32(d * rng.uniform(0.05, 12, size=(n, 1)))
-    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=2)
+    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=0, name="505 spheres, 20k rays from above", t_tol=3.4e-6, p_tol=4.3e-6, n_tol=8.8e-5)
     # rays leaving the surfaces (secondary rays), starting just above the hit point
     r0 = orc.scan(hs, o, d)
     sel = r0["idx"] >= 0
     p0 = f32(r0["p"][sel] + 1e-3 * r0["n"][sel])
     d1 = f32(rng.normal(size=p0.shape))
-    check_scan(dev.scan(p0, d1), orc.scan(hs, p0, d1), allow_mismatch=2)
+    check_scan(dev.scan(p0, d1), orc.scan(hs, p0, d1), allow_mismatch=2, name="505 spheres, secondary rays", t_tol=1.6e-5, p_tol=1.4e-6, n_tol=7e-6)
     orc.scene_free(hs)
 
 
 def test_scan_rays_from_far_away(dev, orc):
     """Rays that start hundreds of units out (a bounce off the far ground) and aim at the small spheres: the scan
     works from the point of the ray's line nearest the world origin, so the distance of the start does not eat
-    the digits of the discriminant. An fp32 direction still places the hit point to ~|o| * 6e-8, which a sphere of
-    radius 0.1 turns into a few 1e-4 of normal; index, t and point keep the 1e-4 bar."""
+    the digits of the discriminant: no sphere is mistaken for another (0 of 6,000; 349 with the textbook form).
+    The normal cannot keep 1e-4 here whatever the kernel does: the ray's direction is an fp32 vector, so after
+    |o| ~ 300-420 units the point where it arrives is uncertain by |o| x 2^-24 ~ 2.5e-5, and a sphere of radius 0.1
+    turns that into 2.5e-4 of normal (measured 3.1e-4). t and the point keep north_star's 1e-4."""
     from path_tracer_amd import host
     sc = host.generate_scene(500, 1, 2)
     use(dev, sc, host.camera_setup())
@@ -160,14 +178,8 @@ def test_scan_rays_from_far_away(dev, orc):
     d = f32(aim - far)
     out, ref = dev.scan(far, d), orc.scan(hs, far, d)
     orc.scene_free(hs)
-    mism = out["idx"] != ref["idx"]
-    assert mism.sum() <= 8, mism.sum()
-    hit = ~mism & (ref["idx"] >= 0)
+    hit = check_scan(out, ref, allow_mismatch=0, name="rays from 300 units away", t_tol=9e-7, p_tol=7.8e-5, n_tol=FAR_N_TOL)
     assert hit.sum() > 0.5 * n and (ref["idx"][hit] > 4).sum() > 0.2 * n        # plenty of small spheres among the hits
-    assert (np.abs(out["t"][hit] - ref["t"][hit]) / ref["t"][hit]).max() < REL
-    assert vec_rel_err(out["p"][hit], ref["p"][hit]).max() < REL
-    assert np.abs(out["n"][hit] - ref["n"][hit]).max() < 2e-3
-    assert np.array_equal(out["front"][hit], ref["front"][hit])
 
 
 def test_scan_kats_and_edges(dev, orc, kat):
@@ -199,7 +211,7 @@ def test_scan_kats_and_edges(dev, orc, kat):
         hs = orc.scene_create(sc)
         o = np.zeros((512, 3))
         d = f32(np.stack([rng.uniform(-0.6, 0.6, 512), rng.uniform(-0.6, 0.6, 512), -np.ones(512)], axis=1))
-        check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=1)
+        check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=0, name="%d spheres (padding)" % n, t_tol=5.4e-7, p_tol=6.8e-7, n_tol=4.1e-6)
         orc.scene_free(hs)
 
 
@@ -207,8 +219,9 @@ def test_scatter_T4_fixture(dev):
     g = np.load(os.path.join(GOLDEN, "t4_scatter.npz"))
     s = dev.scatter(g["kind"], g["albedo"], g["fuzz"], g["ior"], g["d_in"], g["p"], g["nrm"], g["front"], g["u"])
     assert np.array_equal(s["ok"], g["r_ok"])
-    assert vec_rel_err(s["d"], g["r_d"]).max() < REL
-    assert np.abs(s["atten"] - g["r_atten"]).max() < 1e-7
+    m = dict(d=float(vec_rel_err(s["d"], g["r_d"]).max()), atten=float(np.abs(s["atten"] - g["r_atten"]).max()))
+    print("[measured] T4 scatter fixture: %s" % m)
+    assert m["d"] < 1e-6 and m["atten"] == 0.0, m                 # measured 4.8e-7; the albedos of the fixture are fp32 values
     for kind in (0, 1, 2):
         assert (g["kind"] == kind).sum() > 100
 
@@ -232,6 +245,31 @@ def test_scatter_kats(dev, kat):
     assert s["ok"][0] == 0
 
 
+def test_round2_hand_derived_kats_on_the_device(dev, orc, kat):
+    """The vectors added to kat.json in round 2 (TIR, oblique refraction, Schlick at cos 0.5, fuzzed metal, the
+    Lambertian guard, pixel -> ray for a 2-pixel-wide image with an axis-aligned camera): the device answers them to
+    fp32 accuracy. The CPU suite asserts the same vectors on the oracle (tests/test_oracle.py)."""
+    import kat_cases
+    worst = kat_cases.run_scatter_cases(dev.scatter, kat, atol=1e-7)        # measured 4.8e-8
+    print("scatter KATs: largest deviation %.2e" % worst)
+    k = kat["camera_axis_aligned"]
+    cam = np.array(k["pos"] + k["lower_left"] + k["horizontal"] + k["vertical"] + k["u"] + k["v"] + [k["lens_radius"]], dtype=np.float64)
+    dev.set_camera(cam)                                              # the hand-derived constants themselves
+    p = kat["pixel_to_ray"]
+    for r in p["rays"]:
+        o, d = dev.gen_ray(p["width"], p["height"], [r["i"]], [r["j"]], [r["u1"]], [r["u2"]], [r["disk"][0]], [r["disk"][1]])
+        assert np.abs(o[0] - r["o"]).max() < 1e-6 and np.abs(d[0] - r["d"]).max() < 1e-6, (r, o, d)
+    # the first random sphere of seed 5489 (evaluated from the published mt19937 outputs) is hit where the arithmetic says
+    from path_tracer_amd import host
+    want = kat_cases.first_random_sphere(kat)
+    sc = host.generate_scene(1, 5489, 5489)
+    use(dev, sc, host.camera_setup())
+    c = np.array([want["cx"], want["r"], want["cz"]])
+    r = dev.scan([c + [0, 5, 0]], [[0, -2, 0]])                      # straight down onto its top: t = (5 - r) / 2
+    assert r["idx"][0] == 5 and r["t"][0] == pytest.approx((5 - want["r"]) / 2, rel=1e-6)
+    assert np.allclose(r["n"][0], [0, 1, 0], atol=1e-6) and np.allclose(r["p"][0], c + [0, want["r"], 0], atol=1e-5)
+
+
 def test_scatter_dielectric_regimes(dev, orc):
     """Total internal reflection, the un-normalised-cosine quirk and Schlick, against the oracle."""
     rng = np.random.default_rng(11)
@@ -251,8 +289,10 @@ def test_scatter_dielectric_regimes(dev, orc):
     args = (kind, np.ones((n, 3)), np.zeros(n), np.full(n, 1.5), d, np.zeros((n, 3)), nrm, front, u)
     g, r = dev.scatter(*args), orc.scatter(*args)
     # a coin that lands within fp32 rounding of the reflectance may flip: allow a handful
-    same = vec_rel_err(g["d"], r["d"]) < REL
-    assert (~same).sum() <= 3, (~same).sum()
+    err = vec_rel_err(g["d"], r["d"])
+    same = err < REL
+    print("[measured] dielectric regimes: %d of %d coins flipped, largest deviation of the rest %.2e" % ((~same).sum(), n, err[same].max()))
+    assert (~same).sum() == 0 and err.max() < 2.3e-6, ((~same).sum(), err.max())     # measured: no coin flips, 1.14e-6
     assert np.all(g["ok"] == 1)
 
 
@@ -280,12 +320,14 @@ def test_frame_same_numbers_as_oracle(dev, orc, scene250):
     until an fp32 rounding flips a discrete decision."""
     sc, cam, hs = scene250
     img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 96, 54, 8, 50)
-    assert med < 2e-6 and frac_off < 0.02, (med, frac_off)
-    assert abs(img.mean() - ref.mean()) < 0.002 * ref.mean()
-    assert abs(rays - ref_rays) < 0.005 * ref_rays
+    print("[measured] frame 96x54x8 under identical numbers: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
+          % (med, frac_off, rays, ref_rays, img.mean() / ref.mean()))
+    assert med < 5e-8 and frac_off < 0.0028, (med, frac_off)                  # measured 2.4e-8, 0.0014
+    assert abs(img.mean() - ref.mean()) < 3e-5 * ref.mean()                    # measured 1.5e-5
+    assert abs(rays - ref_rays) < 2e-4 * ref_rays                              # measured 8 of 99,119
     g = np.load(os.path.join(GOLDEN, "t6b_philox_96x54.npz"))
     d = np.abs(img.astype(np.float64) - g["sum"]).max(axis=2) / 8
-    assert (d > 2e-3).mean() < 0.02 and abs(rays - int(g["rays"])) < 0.005 * int(g["rays"])
+    assert (d > 2e-3).mean() < 0.0028 and abs(rays - int(g["rays"])) < 2e-4 * int(g["rays"])
 
 
 def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
@@ -294,8 +336,10 @@ def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
     cam = host.camera_setup(aspect=101 / 57)
     sc = host.generate_scene(250, 3, 4, diffuse_below=0.1, metal_below=0.5)
     img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 101, 57, 4, 100, key0=7, key1=9)
-    assert med < 5e-6 and frac_off < 0.05, (med, frac_off)
-    assert abs(img.mean() - ref.mean()) < 0.005 * ref.mean() and abs(rays - ref_rays) < 0.01 * ref_rays
+    print("[measured] glass-heavy frame 101x57x4: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
+          % (med, frac_off, rays, ref_rays, img.mean() / ref.mean()))
+    assert med < 5e-8 and frac_off < 0.0034, (med, frac_off)                  # measured 2.4e-8, 0.0017
+    assert abs(img.mean() - ref.mean()) < 2e-5 * ref.mean() and abs(rays - ref_rays) < 1e-3 * ref_rays   # measured 1.0e-5, 26 of 56,888
 
 
 def test_glass_heavy_scene_statistics(dev, orc):
@@ -486,12 +530,13 @@ def test_large_scene_10k_spheres(dev, orc):
     o = f32(np.stack([rng.uniform(-40, 40, n), rng.uniform(0.5, 4, n), rng.uniform(-40, 40, n)], axis=1))
     d = rng.normal(size=(n, 3)); d[:, 1] = -np.abs(d[:, 1]) * 0.3
     d = f32(d)
-    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=2)
+    check_scan(dev.scan(o, d), orc.scan(hs, o, d), allow_mismatch=2, name="9,912 spheres, 4k rays", t_tol=8.4e-7, p_tol=8.8e-7, n_tol=2e-5)
     img, rays = dev.render_image(64, 36, 2, 50, seed=(2 << 32) | 1)
     ref, _, ref_rays = orc.render(hs, cam, 64, 36, 0, 2, 50, mode=1, seed_a=1, seed_b=2, threads=os.cpu_count() or 1)
     orc.scene_free(hs)
     diff = np.abs(img - ref).max(axis=2) / 2
-    assert (diff > 2e-3).mean() < 0.03 and abs(rays - ref_rays) < 0.01 * ref_rays
+    print("[measured] 9,912-sphere frame 64x36x2: pixels off by > 2e-3: %.4f, rays %d vs %d" % ((diff > 2e-3).mean(), rays, ref_rays))
+    assert (diff > 2e-3).mean() < 0.0044 and abs(rays - ref_rays) < 3.5e-3 * ref_rays      # measured 0.0022, 22 of 12,604
 
 
 def test_output_stage_on_device_is_byte_exact(dev, scene250):

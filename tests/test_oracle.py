@@ -188,3 +188,54 @@ def test_mt_and_philox_renders_agree_statistically(orc):
     var = g["var"].astype(np.float64) * (1.0 / spp + 1.0 / int(g["spp"]))
     chi = ((mean - g["mean"]) ** 2).sum() / var.sum()
     assert 0.8 < chi < 1.2, chi
+
+
+# ---- hand-derived vectors added in round 2 (tests/golden/kat.json, tests/kat_cases.py); the same on the device in test_gpu_parity.py ----
+def test_round2_scatter_kats_on_the_oracle(orc, kat):
+    import kat_cases
+    assert len(kat_cases.scatter_cases(kat)) >= 7
+    assert kat_cases.run_scatter_cases(orc.scatter, kat, atol=1e-13) < 1e-13
+
+
+def test_round2_camera_and_pixel_kats_on_the_oracle_and_the_host(orc, kat):
+    from path_tracer_amd import host
+    k = kat["camera_axis_aligned"]
+    kw = dict(pos=k["pos"], look=k["look"], up=k["up"], aspect=k["aspect"], focal=k["focal"], fov=k["fov"], aperture=k["aperture"], focus=k["focus"])
+    for cam in (orc.camera_setup(**kw), host.camera_setup(**kw)):
+        want = np.array(k["pos"] + k["lower_left"] + k["horizontal"] + k["vertical"] + k["u"] + k["v"] + [k["lens_radius"]], dtype=np.float64)
+        assert np.abs(cam - want).max() <= k["tolerance"], cam
+    cam = orc.camera_setup(**kw)
+    p = kat["pixel_to_ray"]
+    for r in p["rays"]:
+        o, d = orc.gen_ray(cam, p["width"], p["height"], [r["i"]], [r["j"]], [r["u1"]], [r["u2"]], [r["disk"][0]], [r["disk"][1]])
+        assert np.abs(o[0] - r["o"]).max() < 1e-12 and np.abs(d[0] - r["d"]).max() < 1e-12, (r, o, d)
+
+
+def test_round2_first_random_sphere_from_published_mt19937_outputs(orc, kat):
+    import kat_cases
+    from path_tracer_amd import host
+    k = kat["first_random_sphere_seed_5489"]
+    for i, v in enumerate(k["mt19937_first_outputs"]):
+        assert orc.mt19937_nth(5489, i + 1) == v
+    want = kat_cases.first_random_sphere(kat)
+    for name, approx in k["approx"].items():                             # the hand-rounded values of the derivation
+        got = {"selector": want["selector"], "radius": want["r"], "x": want["cx"], "z": want["cz"]}[name]
+        assert abs(got - approx) < 5e-4, (name, got, approx)
+    for gen in (orc.generate_scene, host.generate_scene):
+        sc = gen(1, k["seed_a"], k["seed_b"])
+        assert len(sc["kind"]) == 6
+        assert sc["cx"][5] == want["cx"] and sc["cy"][5] == want["r"] and sc["cz"][5] == want["cz"] and sc["r"][5] == want["r"]   # bit-exact
+        assert sc["kind"][5] == 0 and [sc["ar"][5], sc["ag"][5], sc["ab"][5]] == want["albedo"]
+
+
+def test_round2_config_quirk_kats(kat):
+    from path_tracer_amd import host
+    from test_host import REFERENCE_CONFIG
+    k = kat["config_quirks"]
+    for name in ("signed_vector", "exponent_vector"):
+        ok, v = host.read_vector(k[name]["text"])
+        assert int(ok) == k[name]["ok"] and list(v) == k[name]["value"]
+    m = k["missing_key_keeps_up_orient"]
+    txt = REFERENCE_CONFIG.replace("(0,1,0)\t", "(%d,%d,%d)\t" % tuple(m["up_in_file"])).replace(m["missing"], m["missing"] + "X").replace("= 400", "= 999")
+    s, used_defaults = host.read_settings(txt)
+    assert used_defaults and list(s["cameraUpOrient"]) == m["up_after"] and s["imageWidth"] == m["width_after"]
