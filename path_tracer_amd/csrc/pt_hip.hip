@@ -583,10 +583,10 @@ __global__ void k_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, u
 // Device memory the sample loop needs beyond its inputs and outputs: the planar u64[3][H][W] job sums and two
 // counters (rays of the call, next job). pt_render keeps them in buffers it allocates; pt_render_noalloc uses this
 // array instead, one copy per GPU, held until the process ends (PT_NOALLOC_MAX_PIXELS from include/pt_hip.h:
-// 1.5 MB + 49.8 MB). The counters and the queue between k_render<0> and k_tail (RenderParams::counters), then the sums.
+// 3.1 MB + 49.8 MB). The counters and the slots between k_render<0> and k_tail (RenderParams::counters), then the sums.
 #define PT_SCRATCH_COUNTER_WORDS PT_COUNTER_WORDS
 #define PT_MAX_DEVICES 64
-#define PT_SCRATCH_TAIL_ENTRIES (8192 * PT_TAIL_PATHS)          // 8 waves on each of the 1,024 SIMDs, PT_TAIL_PATHS paths each: 1.5 MB
+#define PT_SCRATCH_TAIL_ENTRIES (8192 * PT_TAIL_PATHS)          // 8 waves on each of the 1,024 SIMDs, PT_TAIL_PATHS slots each: 3.1 MB
 #define PT_SCRATCH_HEAD_WORDS (PT_SCRATCH_COUNTER_WORDS + PT_SCRATCH_TAIL_ENTRIES * (sizeof(TailPath) / 8))
 static __device__ __align__(256) unsigned long long scratch[PT_SCRATCH_HEAD_WORDS + 3 * size_t(PT_NOALLOC_MAX_PIXELS)];
 

@@ -493,6 +493,33 @@ def test_full_size_properties(dev, orc):
     assert rays2 == rays and np.array_equal(img, img2)
 
 
+def test_reference_default_frame_400x225_100spp(dev, orc):
+    """configs[0]'s frame on the device: the reference's own defaults (config.txt: 400 wide, aspect 16:9 -> 225 rows,
+    100 rays per pixel, depth 50; Path Tracer.cpp:114-133, :199: 5 fixed + 250 random spheres). 225 = 28 x 8 + 1, so the
+    bottom row of tiles holds one row of pixels (the compact job enumeration), and the frame is small enough for the
+    end-of-frame hand-over to k_tail to matter. The first 8 samples per pixel against the oracle drawing the same
+    philox numbers; all 100 against that oracle's rays per sample and luminance."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(250, 1, 2)
+    cam = host.camera_setup(aspect=1.7777777777)
+    W, H, depth = 400, int(400 / 1.7777777777), 50
+    assert H == 225 and len(sc["kind"]) == 255
+    img8, ref8, rays8, ref_rays8, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, W, H, 8, depth, key0=3, key1=5)
+    print("[measured] 400x225x8 under identical numbers: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
+          % (med, frac_off, rays8, ref_rays8, img8.mean() / ref8.mean()))
+    assert med < 5e-8 and frac_off < 0.0016                                    # measured 2.4e-8, 0.0008
+    assert abs(rays8 - ref_rays8) < 1.3e-4 * ref_rays8 and abs(img8.mean() / ref8.mean() - 1) < 3e-6     # measured 6.5e-5, 1e-6
+    assert np.abs(img8[H - 1] - ref8[H - 1]).max() / 8 < 0.2 and img8[H - 1].any()   # the one-row tiles at the bottom are filled
+    img, rays = dev.render_image(W, H, 100, depth, seed=(5 << 32) | 3)
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 100 * 1.0001
+    rps, rps_ref = rays / (W * H * 100), ref_rays8 / (W * H * 8)
+    lum, lum_ref = img.mean() / 100, ref8.mean() / 8
+    print("[measured] 400x225x100: rays per sample %.4f (oracle at 8 spp %.4f), luminance %.5f (%.5f)" % (rps, rps_ref, lum, lum_ref))
+    assert abs(rps / rps_ref - 1) < 1e-4 and abs(lum / lum_ref - 1) < 3e-4    # measured 4e-5 and 1.4e-4 (noise of the 8-spp estimate: ~1e-3)
+    again, rays_again = dev.render_image(W, H, 100, depth, seed=(5 << 32) | 3)
+    assert rays_again == rays and np.array_equal(again, img)                 # whatever the scheduling and the hand-over
+
+
 def test_4k_frame_split_across_sample_ranges(dev):
     """configs[2] at full width and height (3840x2160; 32 spp instead of 1024, the properties do not depend on it):
     the frame rendered as 8 disjoint sample ranges (what 8 GPUs do) and summed equals the frame rendered in one

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Run ON THE GPU BOX: the round's numbers for DESIGN.md section 6 (one box, one call).
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 400 python3 bench.py --steps 10 > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload configs2 --no-extras --no-cpu-baseline > gpurun_out/r02_bench_configs2.json 2>> gpurun_out/r02_bench.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --workload configs4 --no-extras --no-cpu-baseline > gpurun_out/r02_bench_configs4.json 2>> gpurun_out/r02_bench.err || exit 1
+timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --spp 1024 --no-extras --no-cpu-baseline > gpurun_out/r02_bench_1080p_1024spp.json 2>> gpurun_out/r02_bench.err || exit 1
+echo "configs3:"; DIFFUSE=0.1 METAL=0.5 DEPTH=100 REPS=8 timeout -k 10 120 python3 tools/perf_run.py | tail -1
+echo "small:"; W=400 H=225 SPHERES=250 SPP=100 REPS=40 timeout -k 10 120 python3 tools/perf_run.py | tail -1 | sed 's/.*\]//'
+timeout -k 10 120 path_tracer_amd/lib/pathtracer tools/configs/4k_p3.txt /tmp/o3.ppm && timeout -k 10 120 path_tracer_amd/lib/pathtracer tools/configs/4k_p6.txt /tmp/o6.ppm
