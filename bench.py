@@ -259,6 +259,8 @@ def main():
     if host_reduce:
         local_rank = 0
     if not no_gpu:
+        # a launcher that gives every rank its own visible device (HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
     ptd.init("gloo" if host_reduce else "nccl")   # "nccl" is RCCL; a single process needs no group
 

@@ -19,20 +19,21 @@ def split_range(total_spp, world, rank):
     return (total_spp * rank) // world, (total_spp * (rank + 1)) // world
 
 
-def init(backend=None):
+def init(backend=None, force=False):
     """Joins the process group described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*. Returns
-    (rank, local_rank, world). A single process needs no group."""
+    (rank, local_rank, world). A single process needs no group (force=True makes one anyway: a one-rank
+    RCCL group exercises the same calls as N ranks, which a one-GPU box can otherwise not run)."""
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {}
         if backend in (None, "nccl"):
             import torch
             backend = "nccl"
-            kw["device_id"] = torch.device("cuda", local_rank)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())   # the caller has set the rank's device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 

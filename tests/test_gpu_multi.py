@@ -101,6 +101,43 @@ def test_bench_two_ranks_through_its_own_launcher():
     assert 2.0 < s["rays_per_sample"] < 3.2
 
 
+_RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+from path_tracer_amd import Device, host, distributed as ptd
+torch.cuda.set_device(0)
+rank, _, world = ptd.init("nccl", force=True)          # "nccl" is RCCL on ROCm
+assert dist.get_backend() == "nccl" and (rank, world) == (0, 1)
+W, H = 160, 90
+dev = Device(0)
+dev.set_scene(host.generate_scene(250, 1, 2)); dev.set_camera(host.camera_setup())
+dev.set_stream(torch.cuda.current_stream().cuda_stream)
+accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+dev.render(W, H, 0, 4, 50, 42, accum_ptr=accum.data_ptr())
+before = accum.clone()
+dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)        # what ptd.reduce_frame issues with more than one rank
+torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+r = torch.tensor([dev.ray_count()], dtype=torch.int64, device="cuda"); dist.all_reduce(r, op=dist.ReduceOp.SUM)
+assert torch.equal(accum, before) and before.any() and float(t.item()) == 1.5 and int(r.item()) == dev.ray_count()
+dist.barrier(); dist.destroy_process_group(); dev.close()
+print("rccl one-rank ok")
+'''
+
+
+def test_one_rank_rccl_group_runs_the_collectives_of_the_bench(tmp_path):
+    """RCCL takes one rank per GPU, so a one-GPU box cannot run two ranks; a one-rank group still goes through the same
+    init (device_id), reduce, barrier and all_reduce calls on device tensors that bench.py makes with N ranks."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(_RCCL_ONE_RANK % {"root": ROOT})
+    env = dict(os.environ)
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0 and b"rccl one-rank ok" in p.stdout, p.stderr.decode()[-3000:]
+
+
 def test_pt_reduce_argument_checks_on_one_gpu():
     from path_tracer_amd import Device, PtError, host
     from path_tracer_amd._capi import reduce, reduce_stats
