@@ -79,13 +79,15 @@ struct CameraDev {         // Camera.cpp:27-31, as floats; ll_rel = lowerLeft - 
 // (Path Tracer.cpp:48-52), RNG-B (VectorFunc.cpp:15-19) and RNG-C (Dielectric.cpp:52-56).
 // ---------------------------------------------------------------------------------------------
 struct u4 { uint32_t x, y, z, w; };
+// a ^ b ^ c in one instruction (v_bitop3_b32 with the truth table of a three-way xor); the compiler leaves two.
+PT_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 PT_DEV u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = uint64_t(0xD2511F53u) * c0;
         uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
-        uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n0 = xor3(uint32_t(p1 >> 32), c1, k0);
+        uint32_t n2 = xor3(uint32_t(p0 >> 32), c3, k1);
         c1 = uint32_t(p1);
         c3 = uint32_t(p0);
         c0 = n0;
@@ -133,14 +135,26 @@ PT_DEV f3 sky(float dy) {
 // ---------------------------------------------------------------------------------------------
 // Tier 2 for one flagged sphere: Sphere.cpp:16-23 and HittableList.cpp:28-31 in unit-direction t.
 // ---------------------------------------------------------------------------------------------
-PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_t, int& best_i) {
+// T = r^2 - dist(c, line)^2, b = position of the sphere's centre along the line (measured from p), tmin likewise.
+// The closest hit so far is kept as best_d = its distance BEYOND tmin (>= 0, +inf for none). The two roots beyond tmin
+// are b' -+ sqrt(T) with b' = b - tmin; the reference takes the near one unless it lies before tmin, then the far one,
+// and rejects that too if it lies before tmin (Sphere.cpp:17-21): "the smallest non-negative of the two". Negative
+// floats (and NaNs, for T < 0: Sphere.cpp:13) compare LARGER than every non-negative float when their bits are read as
+// unsigned integers, so that choice is one unsigned minimum, and "within [0, best_d]" one unsigned compare.
+PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_d, int& best_i) {
     asm volatile("" : "+s"(j));   // keep j a scalar register: hipcc otherwise rewrites `j != prev` into a vector add per quad in tier 1
-    float s = fast_sqrt(T);                                       // NaN for T < 0 (Sphere.cpp:13): t1, t2, t are NaN and every compare below is false
-    float t1 = b - s, t2 = b + s;
-    float t = (t1 >= tmin) ? t1 : t2;                              // Sphere.cpp:17-19
-    bool ok = (j != prev) & (t >= tmin) & (t <= best_t);           // :20; <= : later index wins ties
-    best_t = ok ? t : best_t;
-    best_i = ok ? j : best_i;
+    const float s = fast_sqrt(T);
+    const float bp = b - tmin;
+    const float t1 = bp - s, t2 = bp + s;                                            // Sphere.cpp:17, :19
+    uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
+    const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));                   // :18-21; <= : later index wins ties
+    // Two moves under the execution mask instead of two selects and a scalar-to-vector copy of j (the empty asm keeps
+    // hipcc from turning the branch back into selects): one vector instruction fewer per flagged sphere.
+    if (ok) {
+        asm volatile("" : "+v"(tu));
+        best_d = __uint_as_float(tu);
+        best_i = j;
+    }
 }
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -155,9 +169,9 @@ PT_DEV v16f sload16(const float* p) {
 PT_DEV void swait(v16f& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
 
 // Tier 1 and, when flagged, tier 2 for the four spheres of one record quad R (spheres j .. j+3).
-// dh: unit direction; ne = -p.dh, p2 = 2 p, pp = |p|^2 with p the foot point of the line; tmin and best_t are
-// distances along the line measured from p.
-PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float ne, f3 p2, float pp, int prev, float tmin, float& best_t,
+// dh: unit direction; ne = -p.dh, p2 = 2 p, pp = |p|^2 with p the foot point of the line; tmin is a distance along
+// the line measured from p, best_d the closest hit's distance beyond tmin (see tier2).
+PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float ne, f3 p2, float pp, int prev, float tmin, float& best_d,
                       int& best_i) {
     // Seven packed FMAs per sphere pair, each with exactly one scalar operand:
     //   a = c.dh - p.dh;  U = a*a + (-K) + 2 p.c  ( = T + |p|^2 );  the line meets the sphere iff U >= |p|^2.
@@ -184,10 +198,10 @@ PT_DEV void scan_quad(const v16f& R, int j, f3 dh, float ne, f3 p2, float pp, in
 #endif
     if (__any(m >= pp)) {                       // wave-uniform: some lane's line meets a sphere of this quad
         // one wave-uniform branch per sphere, so that the three spheres nobody flagged cost a compare each
-        if (__any(U[0].x >= pp)) tier2(U[0].x - pp, B[0].x, j + 0, prev, tmin, best_t, best_i);
-        if (__any(U[0].y >= pp)) tier2(U[0].y - pp, B[0].y, j + 1, prev, tmin, best_t, best_i);
-        if (__any(U[1].x >= pp)) tier2(U[1].x - pp, B[1].x, j + 2, prev, tmin, best_t, best_i);
-        if (__any(U[1].y >= pp)) tier2(U[1].y - pp, B[1].y, j + 3, prev, tmin, best_t, best_i);
+        if (__any(U[0].x >= pp)) tier2(U[0].x - pp, B[0].x, j + 0, prev, tmin, best_d, best_i);
+        if (__any(U[0].y >= pp)) tier2(U[0].y - pp, B[0].y, j + 1, prev, tmin, best_d, best_i);
+        if (__any(U[1].x >= pp)) tier2(U[1].x - pp, B[1].x, j + 2, prev, tmin, best_d, best_i);
+        if (__any(U[1].y >= pp)) tier2(U[1].y - pp, B[1].y, j + 3, prev, tmin, best_d, best_i);
     }
 }
 
@@ -203,9 +217,10 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     const f3 p2 = p * 2.0f;
     const float pp = dot(p, p);
     const float shift = od;                      // distance from p to o along the line: t = tau - shift
+    const float tmin_ray = tmin;
     tmin += shift;
     self_t += shift;
-    best_t = __builtin_inff();
+    float best_d = __builtin_inff();             // the closest hit's distance beyond tmin
     best_i = -1;
     // The scan records come through the scalar cache, one s_load_dwordx16 (four spheres) at a time, in two
     // register banks: the request for the next quad is issued right after the wait that delivers the
@@ -219,21 +234,22 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
     for (int j = 0; j < n_pad; j += 8) {
         swait(bankA);
         v16f bankB = sload16(rec + 16);
-        scan_quad(bankA, j, dh, ne, p2, pp, prev, tmin, best_t, best_i);
+        scan_quad(bankA, j, dh, ne, p2, pp, prev, tmin, best_d, best_i);
         swait(bankB);
         bankA = sload16(rec + 32);
-        if (j + 4 < n_pad) scan_quad(bankB, j + 4, dh, ne, p2, pp, prev, tmin, best_t, best_i);
+        if (j + 4 < n_pad) scan_quad(bankB, j + 4, dh, ne, p2, pp, prev, tmin, best_d, best_i);
         rec += 32;
     }
     swait(bankA);                                // the last request (never-hit padding) must land before the registers are reused
     // The sphere the ray starts on: the near root is the start point (rejected by t_min in the
     // reference), the far root counts only when the ray heads into the sphere.
     {
-        bool ok = (prev >= 0) & (self_t >= tmin) & (self_t <= best_t);
-        best_t = ok ? self_t : best_t;
+        const float sd = self_t - tmin;
+        bool ok = (prev >= 0) & (sd >= 0.0f) & (sd <= best_d);
+        best_d = ok ? sd : best_d;
         best_i = ok ? prev : best_i;
     }
-    best_t -= shift;                             // back to the ray's own (approximate) t; inf stays inf
+    best_t = best_d + tmin_ray;                  // back to the ray's own (approximate) t; inf stays inf
 }
 
 // The same search with the SPHERES spread over a GROUP of G lanes that all hold the same ray (every argument the
@@ -251,9 +267,10 @@ PT_DEV void coop_scan(RecPtr scan, int n_pad, int sub, f3 o, f3 dh, float tmin, 
     const f3 p2 = p * 2.0f;
     const float pp = dot(p, p);
     const float shift = od;
+    const float tmin_ray = tmin;
     tmin += shift;
     self_t += shift;
-    best_t = __builtin_inff();
+    float best_d = __builtin_inff();
     best_i = -1;
     const int n_quads = n_pad >> 2;
     for (int q = sub; q < n_quads; q += G) {
@@ -274,29 +291,31 @@ PT_DEV void coop_scan(RecPtr scan, int n_pad, int sub, f3 o, f3 dh, float tmin, 
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int j = 4 * q + 2 * h + k;
-                const float s = fast_sqrt(u[k] - pp);              // NaN for a line that misses: every compare below is false
-                const float t1 = b[k] - s, t2 = b[k] + s;
-                const float t = (t1 >= tmin) ? t1 : t2;
-                const bool ok = (j != prev) & (t >= tmin) & (t <= best_t);   // j rises within a lane: <= keeps the later index
-                best_t = ok ? t : best_t;
+                const float s = fast_sqrt(u[k] - pp);              // NaN for a line that misses: its bits are above +inf's
+                const float bp = b[k] - tmin;                      // the arithmetic of tier2, operation for operation
+                const float t1 = bp - s, t2 = bp + s;
+                const uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
+                const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));   // j rises within a lane: <= keeps the later index
+                best_d = ok ? __uint_as_float(tu) : best_d;
                 best_i = ok ? j : best_i;
             }
         }
     }
 #pragma unroll
     for (int s = G / 2; s > 0; s >>= 1) {
-        const float ot = __shfl_xor(best_t, s);
+        const float ot = __shfl_xor(best_d, s);
         const int oi = __shfl_xor(best_i, s);
-        const bool take = (ot < best_t) | ((ot == best_t) & (oi > best_i));
-        best_t = take ? ot : best_t;
+        const bool take = (ot < best_d) | ((ot == best_d) & (oi > best_i));
+        best_d = take ? ot : best_d;
         best_i = take ? oi : best_i;
     }
     {
-        bool ok = (prev >= 0) & (self_t >= tmin) & (self_t <= best_t);
-        best_t = ok ? self_t : best_t;
+        const float sd = self_t - tmin;
+        bool ok = (prev >= 0) & (sd >= 0.0f) & (sd <= best_d);
+        best_d = ok ? sd : best_d;
         best_i = ok ? prev : best_i;
     }
-    best_t -= shift;
+    best_t = best_d + tmin_ray;
 }
 
 // Far root of the sphere a scattered ray starts on. The start point p lies on it, so
