@@ -94,7 +94,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
  * kernels as pt_render, bit-identical sums, with three differences:
  *  - the job sums, the counters and the hand-over slots of the end-of-frame kernel, which pt_render keeps in
  *    buffers it allocates, live in a fixed array inside the library (static __device__: 3 x 8 bytes per pixel
- *    of the largest image + 3.1 MB = 52.9 MB on every GPU the library runs on, held until the process ends):
+ *    of the largest image + 8.4 MB = 58.2 MB on every GPU the library runs on, held until the process ends):
  *    width*height <= PT_NOALLOC_MAX_PIXELS (1920x1080), larger images are rejected with PT_ERR_INVALID;
  *  - accum_rgb_f32 must be the caller's DEVICE buffer (NULL is rejected); ray_count_dev, when not NULL, is
  *    a DEVICE pointer that receives the rays traced by this call, written on the handle's stream; the call

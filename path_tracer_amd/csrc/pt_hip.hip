@@ -45,7 +45,11 @@ static_assert(sizeof(TailPath) == 64, "TailPath is 16 words");
 
 struct RenderParams {
     int W, H;
-    int spp_begin, spp_end, spp_chunk, n_chunks;
+    // Jobs, in the order the counter hands them out: n_coarse layers of (every tile x spp_chunk samples per pixel), then
+    // layers of spp_fine samples per pixel from sample fine_begin on. Waves run at very different speeds (the oldest wave
+    // of a SIMD issues first) and take jobs as they go, so the frame ends within about the length of the LAST jobs:
+    // those are small, the bulk is large (fewer trips to the counter and to the frame).
+    int spp_begin, spp_end, spp_chunk, n_coarse, spp_fine, fine_begin, n_tiles;
     int tiles_x;
     int n_jobs;
     int max_depth;
@@ -132,17 +136,34 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #ifndef PT_GRID_WAVES_PER_EU
 #define PT_GRID_WAVES_PER_EU 5      // 96 registers, no spills; at 8 waves (64) the walk state spills and the kernel runs at half the speed
 #endif
+#ifndef PT_PRIO
+#define PT_PRIO 1
+#endif
 #ifndef PT_TAIL_PATHS
-#define PT_TAIL_PATHS 6             // a wave left with at most this many paths and no job hands them to k_tail
+#define PT_TAIL_PATHS 16            // a wave left with at most this many paths and no job hands them to k_tail
 #endif
 #ifndef PT_GRID_RATIO
 #define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
 #endif
+#ifdef PT_TAILPROF
+__device__ unsigned long long g_rprof[8192 * 4 + 8];
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER_EU) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[2 * 192];
+#ifdef PT_TAILPROF
+    __shared__ unsigned long long rp[3];
+    if (threadIdx.x == 0) { rp[0] = wall_clock64(); rp[1] = 0; rp[2] = 0; }
+#endif
     __shared__ unsigned int wave_number;            // blockIdx.x, parked in LDS until the end of the kernel: the loop has no scalar register for it
     const int lane = threadIdx.x;
+#if PT_PRIO
+    // The oldest wave of a SIMD issues first, and in this kernel the vector ALU is always wanted: the youngest of the six
+    // runs at a tenth of the speed of the oldest (measured: rays per wave 12,000 to 168,000 in one launch) and would still
+    // be in the middle of a large job when every other wave has left. A wave on a large job therefore runs at a higher
+    // priority than one on the small jobs of the end, and that one higher than a wave that only drains its last paths.
+    __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[lane + 64 * i] = 0;
     if (lane == 0) wave_number = blockIdx.x;
@@ -260,13 +281,24 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 }
                 if (job >= P.n_jobs) {
                     no_more_jobs = true;
+#if PT_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef PT_TAILPROF
+                    if (lane == 0) rp[1] = wall_clock64();
+#endif
                 } else {
                     have_new = true;
-                    const int tile = job / P.n_chunks, chunk = job - tile * P.n_chunks;
+                    const int chunk = job / P.n_tiles, tile = job - chunk * P.n_tiles;
                     n_ty = tile / P.tiles_x; n_tx = tile - n_ty * P.tiles_x;
-                    n_s0 = P.spp_begin + chunk * P.spp_chunk;
+                    const bool fine = chunk >= P.n_coarse;
+#if PT_PRIO
+                    if (fine) __builtin_amdgcn_s_setprio(1);
+#endif
+                    n_s0 = fine ? P.fine_begin + (chunk - P.n_coarse) * P.spp_fine : P.spp_begin + chunk * P.spp_chunk;
+                    const int s_end = fine ? min(n_s0 + P.spp_fine, P.spp_end) : min(n_s0 + P.spp_chunk, P.fine_begin);
                     n_vh = min(8, P.H - 8 * n_ty);                                   // rows of the tile inside the image
-                    n_total = 8 * n_vh * (min(n_s0 + P.spp_chunk, P.spp_end) - n_s0);
+                    n_total = 8 * n_vh * (s_end - n_s0);
                 }
             }
             const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need_mask), 0));
@@ -380,6 +412,12 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     unsigned int r = rays;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
+#ifdef PT_TAILPROF
+    if (lane == 0 && blockIdx.x < 8192) {
+        g_rprof[4 * blockIdx.x] = rp[0]; g_rprof[4 * blockIdx.x + 1] = rp[1]; g_rprof[4 * blockIdx.x + 2] = wall_clock64(); g_rprof[4 * blockIdx.x + 3] = r;
+        if (blockIdx.x == 0) g_rprof[8192 * 4] = gridDim.x;
+    }
+#endif
     if (lane == 0 && r) atomicAdd(ray_counter(P), (unsigned long long)r);
 }
 
@@ -396,9 +434,16 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 #define PT_TAIL_LDS_MAX 65536        // a workgroup's LDS limit: the scene copies of k_tail<true> must fit
 // LDS: the scan records, the double-precision spheres and the materials are first copied into LDS (scenes up to a
 // few hundred spheres: 97 bytes per sphere), so that a bounce makes no trip to L2: the tail is pure latency.
+#ifdef PT_TAILPROF
+__device__ unsigned long long g_tprof[8192 * 4 + 8];
+#endif
 template <bool LDS>
 __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
+#ifdef PT_TAILPROF
+    const unsigned long long tp_start = wall_clock64();
+    unsigned long long tp_iters = 0, tp_staged = 0;
+#endif
     extern __shared__ __align__(16) unsigned char tail_lds[];
     const int tid = threadIdx.x, sub = tid & (G - 1);
     const int n_rec_floats = (P.scene.n_pad + 8) * 4;
@@ -414,6 +459,9 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
         for (int i = tid; i < P.scene.n * 2; i += 256) reinterpret_cast<float4*>(l_mat)[i] = gm[i];
         __syncthreads();
     }
+#ifdef PT_TAILPROF
+    tp_staged = wall_clock64();
+#endif
     const int n_groups = int(gridDim.x) * (256 / G);
     int next = int(blockIdx.x) * (256 / G) + tid / G;                     // the slot this group looks at next
     const TailPath* slots = tail_slots(P);
@@ -435,6 +483,9 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
             active = true;
         }
         if (!__any(active)) break;                                        // (waves of a workgroup leave independently: no barrier below)
+#ifdef PT_TAILPROF
+        ++tp_iters;
+#endif
         if (active) {
             if (sub == 0) ++rays;
             float bt; int bi;
@@ -474,7 +525,17 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) rays += __shfl_xor(rays, s);
+#ifdef PT_TAILPROF
+    const unsigned long long tp_loop = wall_clock64();
+#endif
     if ((tid & 63) == 0 && rays) atomicAdd(ray_counter(P), (unsigned long long)rays);
+#ifdef PT_TAILPROF
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (w < 8192) { g_tprof[4 * w] = tp_start; g_tprof[4 * w + 1] = tp_staged; g_tprof[4 * w + 2] = tp_loop; g_tprof[4 * w + 3] = tp_iters; }
+        if (w == 0) g_tprof[8192 * 4] = gridDim.x * 4;
+    }
+#endif
 }
 
 __global__ void k_resolve(unsigned long long* fx, float* out, size_t n_pixels, const unsigned long long* call_rays,
@@ -583,10 +644,10 @@ __global__ void k_philox(int n, const uint32_t* ctr, uint32_t k0, uint32_t k1, u
 // Device memory the sample loop needs beyond its inputs and outputs: the planar u64[3][H][W] job sums and two
 // counters (rays of the call, next job). pt_render keeps them in buffers it allocates; pt_render_noalloc uses this
 // array instead, one copy per GPU, held until the process ends (PT_NOALLOC_MAX_PIXELS from include/pt_hip.h:
-// 3.1 MB + 49.8 MB). The counters and the slots between k_render<0> and k_tail (RenderParams::counters), then the sums.
+// 8.4 MB + 49.8 MB). The counters and the slots between k_render<0> and k_tail (RenderParams::counters), then the sums.
 #define PT_SCRATCH_COUNTER_WORDS PT_COUNTER_WORDS
 #define PT_MAX_DEVICES 64
-#define PT_SCRATCH_TAIL_ENTRIES (8192 * PT_TAIL_PATHS)          // 8 waves on each of the 1,024 SIMDs, PT_TAIL_PATHS slots each: 3.1 MB
+#define PT_SCRATCH_TAIL_ENTRIES (8192 * PT_TAIL_PATHS)          // 8 waves on each of the 1,024 SIMDs, PT_TAIL_PATHS slots each: 8.4 MB
 #define PT_SCRATCH_HEAD_WORDS (PT_SCRATCH_COUNTER_WORDS + PT_SCRATCH_TAIL_ENTRIES * (sizeof(TailPath) / 8))
 static __device__ __align__(256) unsigned long long scratch[PT_SCRATCH_HEAD_WORDS + 3 * size_t(PT_NOALLOC_MAX_PIXELS)];
 
@@ -640,6 +701,9 @@ struct pt_context {
     size_t ev_used = 0;
     int target_jobs = 262144;
     int min_chunk = 4;                          // PT_MIN_CHUNK: fewest samples per pixel in a job
+    int tail_rounds = 1;                        // PT_TAIL_ROUNDS: workgroups of k_tail, in units of what the chip holds at a time
+    int fine_chunk = 2;                         // PT_FINE_CHUNK: samples per pixel in the small jobs at the end of a launch (0: none)
+    int fine_share_pct = 100;                   // PT_FINE_SHARE: their share, in percent of one large job per wave
     int grid_factor_pct = 100;                  // PT_GRID_PCT: persistent grid as a percentage of the resident waves
 };
 
@@ -882,6 +946,9 @@ int pt_create(int device_index, pt_handle* out) {
     }
     if (const char* tj = std::getenv("PT_TARGET_JOBS")) { int v = std::atoi(tj); if (v > 0) h->target_jobs = v; }
     if (const char* mc = std::getenv("PT_MIN_CHUNK")) { int v = std::atoi(mc); if (v > 0) h->min_chunk = v; }
+    if (const char* tr = std::getenv("PT_TAIL_ROUNDS")) { int v = std::atoi(tr); if (v > 0) h->tail_rounds = v; }
+    if (const char* fc = std::getenv("PT_FINE_CHUNK")) { int v = std::atoi(fc); if (v >= 0) h->fine_chunk = v; }
+    if (const char* fs = std::getenv("PT_FINE_SHARE")) { int v = std::atoi(fs); if (v >= 0) h->fine_share_pct = v; }
     if (const char* cs = std::getenv("PT_GRID_CELL_SCALE")) { double v = std::atof(cs); if (v > 0.1 && v < 1000) h->grid_cell_scale = v; }
     if (const char* gf = std::getenv("PT_GRID_FLAT")) h->grid_flat_ok = std::atoi(gf) != 0;
     if (const char* br = std::getenv("PT_GRID_BIG_RATIO")) { double v = std::atof(br); if (v >= 1 && v < 1e6) h->grid_big_ratio = v; }
@@ -1085,8 +1152,23 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         const int min_chunk = h->min_chunk;
         if (want > (spp + min_chunk - 1) / min_chunk) want = (spp + min_chunk - 1) / min_chunk;     // at least min_chunk spp (x 64 items) per job
         P.spp_chunk = int((spp + want - 1) / want);
-        P.n_chunks = (spp + P.spp_chunk - 1) / P.spp_chunk;
-        const long long jobs = tiles * P.n_chunks;
+        const bool use_grid = h->accel == PT_ACCEL_GRID;
+        const int resident = use_grid ? h->resident_waves_grid : h->resident_waves;   // from pt_create
+        // The last jobs are small ones: as many samples as one large job for every wave of the launch (a wave that took
+        // the last large job is then still busy while the others work through the small ones), at most half the call.
+        int fine_spp = 0;
+        P.spp_fine = std::min(h->fine_chunk, P.spp_chunk);
+        if (P.spp_fine > 0 && P.spp_fine < P.spp_chunk) {
+            const long long waves = (long long)resident * h->grid_factor_pct / 100;
+            long long f = (waves * P.spp_chunk * h->fine_share_pct / 100 + tiles - 1) / tiles;
+            f = std::min<long long>((f + P.spp_fine - 1) / P.spp_fine * P.spp_fine, spp / 2 / P.spp_fine * P.spp_fine);
+            fine_spp = int(std::max<long long>(f, 0));
+        }
+        if (fine_spp == 0) P.spp_fine = 1;
+        P.fine_begin = spp_end - fine_spp;
+        P.n_coarse = (spp - fine_spp + P.spp_chunk - 1) / P.spp_chunk;
+        P.n_tiles = int(tiles);
+        const long long jobs = tiles * (P.n_coarse + (fine_spp + P.spp_fine - 1) / P.spp_fine);
         if (jobs > 0x7fffffffLL) return fail(h, PT_ERR_INVALID, "pt_render: too many jobs for one launch");
         P.max_depth = max_depth;
         P.key0 = uint32_t(seed); P.key1 = uint32_t(seed >> 32);
@@ -1095,7 +1177,6 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         P.inv_w1 = 1.0f / float(width - 1); P.inv_h1 = 1.0f / float(height - 1);
         P.cam_dev = h->d_cam;
         P.scene = scene_dev(h);
-        const bool use_grid = h->accel == PT_ACCEL_GRID;
         if (use_grid && !h->grid_ready) return fail(h, PT_ERR_STATE, "pt_render: the grid has not been built");
         if (use_grid) P.grid = h->grid; else std::memset(&P.grid, 0, sizeof(P.grid));
         P.accum_fx = fx;
@@ -1103,7 +1184,6 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         P.n_tail_slots = 0;
         P.n_jobs = int(jobs);
         const bool flat = use_grid && h->grid_info[1] == 1 && h->grid_flat_ok;       // one layer of cells: the walk without a y axis
-        const int resident = use_grid ? h->resident_waves_grid : h->resident_waves;   // from pt_create
         long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
         if (!use_grid) grid = std::min<long long>(grid, (long long)(tail_cap / PT_TAIL_PATHS));      // every wave may queue PT_TAIL_PATHS paths
         // a wave's first job is its own number: the counter starts behind them
@@ -1125,7 +1205,7 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
             const size_t lds = size_t(P.scene.n_pad + 8) * 16 + size_t(P.scene.n) * (sizeof(GeomRec) + sizeof(MatRec));
             const unsigned tail_blocks = unsigned((P.n_tail_slots + 256 / PT_TAIL_GROUP - 1) / (256 / PT_TAIL_GROUP));   // one slot per group
             // with the scene in LDS a compute unit holds 160 KB / lds workgroups at a time: no more than fill the chip once
-            const unsigned lds_blocks = std::min<unsigned>(tail_blocks, unsigned(h->n_cus) * unsigned(std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1))));
+            const unsigned lds_blocks = std::min<unsigned>(tail_blocks, unsigned(h->tail_rounds) * unsigned(h->n_cus) * unsigned(std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1))));
             if (lds <= PT_TAIL_LDS_MAX) hipLaunchKernelGGL(k_tail<true>, dim3(lds_blocks), dim3(256), lds, h->stream, P);
             else hipLaunchKernelGGL(k_tail<false>, dim3(tail_blocks), dim3(256), 0, h->stream, P);
         }
@@ -1182,6 +1262,46 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
                            st[5], st[0] ? double(st[5]) / st[0] : 0.0, double(st[6]) / st[5], double(st[7]) / st[5]);
         unsigned long long z[8] = {0};
         PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)));
+    }
+#endif
+#ifdef PT_TAILPROF
+    {
+        static std::vector<unsigned long long> st(8192 * 4 + 8);
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        PT_HIP(h, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_rprof), st.size() * 8));
+        const size_t nw = std::min<size_t>(8192, st[8192 * 4]);
+        unsigned long long t0 = ~0ull;
+        std::vector<double> nomore, ex;
+        for (size_t w = 0; w < nw; ++w) t0 = std::min(t0, st[4 * w]);
+        double last_start = 0, rays_sum = 0, rays_max = 0;
+        std::vector<double> rw;
+        for (size_t w = 0; w < nw; ++w) {
+            last_start = std::max(last_start, double(st[4 * w] - t0) / 100.0);
+            if (st[4 * w + 1]) nomore.push_back(double(st[4 * w + 1] - t0) / 100.0);
+            ex.push_back(double(st[4 * w + 2] - t0) / 100.0);
+            rays_sum += double(st[4 * w + 3]); rays_max = std::max(rays_max, double(st[4 * w + 3])); rw.push_back(double(st[4 * w + 3]));
+        }
+        std::sort(rw.begin(), rw.end());
+        std::sort(nomore.begin(), nomore.end()); std::sort(ex.begin(), ex.end());
+        auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[size_t(f * (v.size() - 1))]; };
+        fprintf(stderr, "[render prof] waves %zu last start +%.1f us; out of jobs at (min/10%%/50%%/90%%/max) %.0f %.0f %.0f %.0f %.0f us; exit at %.0f %.0f %.0f %.0f %.0f us; rays per wave mean %.0f max %.0f, min/10%%/50%%/90%% %.0f %.0f %.0f %.0f\n",
+                nw, last_start, q(nomore, 0), q(nomore, 0.1), q(nomore, 0.5), q(nomore, 0.9), q(nomore, 1), q(ex, 0), q(ex, 0.1), q(ex, 0.5), q(ex, 0.9), q(ex, 1), rays_sum / nw, rays_max, q(rw, 0), q(rw, 0.1), q(rw, 0.5), q(rw, 0.9));
+    }
+    {
+        static std::vector<unsigned long long> st(8192 * 4 + 8);
+        PT_HIP(h, hipStreamSynchronize(h->stream));
+        PT_HIP(h, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_tprof), st.size() * 8));
+        const size_t nw = std::min<size_t>(8192, st[8192 * 4]);
+        unsigned long long t0 = ~0ull, stage_end = 0, loop_end = 0, last_start = 0, it_max = 0, it_sum = 0, busy = 0;
+        double stage_sum = 0, loop_sum = 0;
+        for (size_t w = 0; w < nw; ++w) {
+            t0 = std::min(t0, st[4 * w]); last_start = std::max(last_start, st[4 * w]);
+            stage_end = std::max(stage_end, st[4 * w + 1]); loop_end = std::max(loop_end, st[4 * w + 2]);
+            it_max = std::max(it_max, st[4 * w + 3]); it_sum += st[4 * w + 3]; busy += st[4 * w + 3] ? 1 : 0;
+            stage_sum += double(st[4 * w + 1] - st[4 * w]); loop_sum += double(st[4 * w + 2] - st[4 * w + 1]);
+        }
+        fprintf(stderr, "[tail prof] waves %zu (with a path %llu): last start +%.1f us, last staged +%.1f us (mean staging %.1f), last loop end +%.1f us (mean loop %.1f us), iterations max %llu mean %.2f\n",
+                nw, busy, (last_start - t0) / 100.0, (stage_end - t0) / 100.0, stage_sum / nw / 100.0, (loop_end - t0) / 100.0, loop_sum / nw / 100.0, it_max, double(it_sum) / nw);
     }
 #endif
     if (ray_count_out) {
