@@ -426,8 +426,10 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 // would run the whole sequential scan for a few lanes at the latency of a lone wave (about 10 us per bounce), with most
 // of the chip idle. Here a path has a GROUP of 16 lanes (four paths per wave): the lanes of a group hold the same path
 // and share out the spheres (coop_scan). Same arithmetic per sphere, same hit rule, same philox blocks, integer sums:
-// the frame is bit for bit what k_render alone would produce. Slots are taken in a fixed order (group g takes g,
-// g + groups, ...): no counter, so nothing for thousands of groups to queue at.
+// the frame is bit for bit what k_render alone would produce. A workgroup owns a run of consecutive slots and its
+// sixteen groups take them one by one through a counter in LDS: a path of fifty bounces then holds up one group while
+// the others work through the rest of the run (with a fixed slot sequence per group the longest sequence, two or three
+// long paths in a row, set the length of the kernel). No global counter, so nothing for thousands of groups to queue at.
 #ifndef PT_TAIL_GROUP
 #define PT_TAIL_GROUP 16
 #endif
@@ -462,8 +464,12 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
 #ifdef PT_TAILPROF
     tp_staged = wall_clock64();
 #endif
-    const int n_groups = int(gridDim.x) * (256 / G);
-    int next = int(blockIdx.x) * (256 / G) + tid / G;                     // the slot this group looks at next
+    __shared__ int run_next;                                              // next slot of this workgroup's run, relative to its start
+    if (tid == 0) run_next = 0;
+    __syncthreads();
+    const int per_block = (P.n_tail_slots + int(gridDim.x) - 1) / int(gridDim.x);
+    const int run_begin = int(blockIdx.x) * per_block, run_end = min(run_begin + per_block, P.n_tail_slots);
+    bool more = true;                                                     // this group has not yet seen the end of the run
     const TailPath* slots = tail_slots(P);
     unsigned int rays = 0;
     bool active = false;
@@ -473,9 +479,12 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     uint32_t pixel = 0, sample = 0, top_pixel = 0;
     for (;;) {
         // a group without a path takes the next occupied slot of its sequence (the lanes of a group read the same words)
-        while (!active && next < P.n_tail_slots) {
-            const TailPath tp = slots[next];
-            next += n_groups;
+        while (!active && more) {
+            int take = 0;
+            if (sub == 0) take = atomicAdd(&run_next, 1);
+            take = __shfl(take, tid & 63 & ~(G - 1)) + run_begin;
+            if (take >= run_end) { more = false; break; }
+            const TailPath tp = slots[take];
             if (tp.bounce < 0) continue;
             o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
             len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
