@@ -44,7 +44,13 @@ stats: $(SRC)
 	@mkdir -p tools/build
 	$(HIPCC) $(HIPFLAGS) -DPT_STATS -shared -o tools/build/libpt_hip_stats.so $< -ldl
 
+# the diagnostic build with per-wave timestamps (when each wave of k_render ran out of jobs and left, how long the groups
+# of k_tail took): PT_HIP_LIB=tools/build/libpt_hip_waveprof.so python3 tools/perf_run.py prints one line per launch
+waveprof: $(SRC)
+	@mkdir -p tools/build
+	$(HIPCC) $(HIPFLAGS) -DPT_WAVEPROF -shared -o tools/build/libpt_hip_waveprof.so $< -ldl
+
 clean:
 	rm -rf $(LIBDIR)/*.so oracle/_build tools/build
 
-.PHONY: all host oracle asm check stats clean
+.PHONY: all host oracle asm check stats waveprof clean

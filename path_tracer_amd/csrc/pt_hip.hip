@@ -145,13 +145,13 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #ifndef PT_GRID_RATIO
 #define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
 #endif
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
 __device__ unsigned long long g_rprof[8192 * 4 + 8];
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER_EU) k_render(const RenderParams P) {
     __shared__ unsigned long long acc[2 * 192];
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     __shared__ unsigned long long rp[3];
     if (threadIdx.x == 0) { rp[0] = wall_clock64(); rp[1] = 0; rp[2] = 0; }
 #endif
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 #if PT_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
                     if (lane == 0) rp[1] = wall_clock64();
 #endif
                 } else {
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     unsigned int r = rays;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     if (lane == 0 && blockIdx.x < 8192) {
         g_rprof[4 * blockIdx.x] = rp[0]; g_rprof[4 * blockIdx.x + 1] = rp[1]; g_rprof[4 * blockIdx.x + 2] = wall_clock64(); g_rprof[4 * blockIdx.x + 3] = r;
         if (blockIdx.x == 0) g_rprof[8192 * 4] = gridDim.x;
@@ -433,16 +433,18 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 #ifndef PT_TAIL_GROUP
 #define PT_TAIL_GROUP 16
 #endif
+#ifndef PT_TAIL_LDS_MAX
 #define PT_TAIL_LDS_MAX 65536        // a workgroup's LDS limit: the scene copies of k_tail<true> must fit
+#endif
 // LDS: the scan records, the double-precision spheres and the materials are first copied into LDS (scenes up to a
 // few hundred spheres: 97 bytes per sphere), so that a bounce makes no trip to L2: the tail is pure latency.
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
 __device__ unsigned long long g_tprof[8192 * 4 + 8];
 #endif
 template <bool LDS>
 __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     const unsigned long long tp_start = wall_clock64();
     unsigned long long tp_iters = 0, tp_staged = 0;
 #endif
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
         for (int i = tid; i < P.scene.n * 2; i += 256) reinterpret_cast<float4*>(l_mat)[i] = gm[i];
         __syncthreads();
     }
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     tp_staged = wall_clock64();
 #endif
     __shared__ int run_next;                                              // next slot of this workgroup's run, relative to its start
@@ -492,7 +494,7 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
             active = true;
         }
         if (!__any(active)) break;                                        // (waves of a workgroup leave independently: no barrier below)
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
         ++tp_iters;
 #endif
         if (active) {
@@ -534,11 +536,11 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) rays += __shfl_xor(rays, s);
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     const unsigned long long tp_loop = wall_clock64();
 #endif
     if ((tid & 63) == 0 && rays) atomicAdd(ray_counter(P), (unsigned long long)rays);
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     if ((threadIdx.x & 63) == 0) {
         const unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (w < 8192) { g_tprof[4 * w] = tp_start; g_tprof[4 * w + 1] = tp_staged; g_tprof[4 * w + 2] = tp_loop; g_tprof[4 * w + 3] = tp_iters; }
@@ -1273,7 +1275,7 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)));
     }
 #endif
-#ifdef PT_TAILPROF
+#ifdef PT_WAVEPROF
     {
         static std::vector<unsigned long long> st(8192 * 4 + 8);
         PT_HIP(h, hipStreamSynchronize(h->stream));
