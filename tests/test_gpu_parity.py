@@ -451,6 +451,40 @@ def test_determinism_linearity_and_split(dev, scene250):
     assert not np.array_equal(a, e)
 
 
+def test_frame_does_not_depend_on_the_job_split(dev, scene250, monkeypatch):
+    """Jobs are an 8x8 tile x a chunk of samples, large ones first and small ones at the end of a launch, handed to
+    whichever wave asks next at one of three priorities; the radiance sums are integers. So the frame and the ray count
+    must be bit for bit the same whatever the job sizes: one chunk per tile, one sample per job, no small jobs, only
+    small jobs; image sizes with partial tiles on both edges; sample ranges shorter than a chunk. (libpt_hip.so reads the
+    settings in pt_create.)"""
+    from path_tracer_amd import Device
+    sc, cam, hs = scene250
+    settings = [dict(),                                                                   # the defaults
+                dict(PT_FINE_CHUNK="0"),                                                  # no small jobs
+                dict(PT_FINE_CHUNK="1", PT_FINE_SHARE="400"),                             # one-sample jobs for half the call
+                dict(PT_TARGET_JOBS="1"),                                                 # one large chunk per tile (+ small ones)
+                dict(PT_TARGET_JOBS="100000000", PT_MIN_CHUNK="1", PT_FINE_CHUNK="0"),    # one sample per job throughout
+                dict(PT_MIN_CHUNK="3", PT_FINE_CHUNK="2", PT_FINE_SHARE="37")]
+    cases = [(200, 113, 0, 16), (67, 35, 3, 10), (8, 8, 0, 1), (33, 9, 5, 7)]
+    want = None
+    for env in settings:
+        for k in ("PT_FINE_CHUNK", "PT_FINE_SHARE", "PT_TARGET_JOBS", "PT_MIN_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = Device(0)
+        try:
+            d.set_scene(sc); d.set_camera(cam)
+            got = [d.render_image(W, H, s1 - s0, 50, seed=31, spp_begin=s0) for (W, H, s0, s1) in cases]
+        finally:
+            d.close()
+        if want is None:
+            want = got
+        else:
+            for (img, rays), (ref_img, ref_rays), case in zip(got, want, cases):
+                assert rays == ref_rays and np.array_equal(img, ref_img), (env, case)
+
+
 def test_external_accumulation_buffer(dev, scene250):
     import torch
     sc, cam, hs = scene250
