@@ -701,6 +701,8 @@ struct pt_context {
     size_t fx_elems = 0;
     float* d_accum = nullptr;
     int acc_w = 0, acc_h = 0;
+    unsigned char* d_ut = nullptr;              // arena of the unit-test entry points (pt_scan, pt_scatter, ...): kept, grows only
+    size_t ut_cap = 0, ut_used = 0;
     unsigned char* d_rgb8 = nullptr;            // output stage (pt_quantise_rgb8): kept between frames, grows only
     size_t rgb8_cap = 0;
     unsigned long long* d_counters = nullptr;   // RenderParams::counters: 8 words ([3] = rays since creation) and the queue of k_tail
@@ -747,10 +749,11 @@ static int upload(pt_handle h, T** dst, const std::vector<T>& src) {
 }
 
 // Scoped device buffer for the unit-test entry points.
+// A device buffer of one unit-test call: a piece of the handle's arena (pt_context::d_ut), which is kept between calls
+// and only grows, so that the host classes, which ask the device one ray or one scatter at a time
+// (host/Material.h, host/HittableList.h), do not pay seven to eleven hipMalloc / hipFree per call.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
@@ -974,7 +977,7 @@ int pt_destroy(pt_handle h) {
     (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     (void)hipFree(h->d_scan); (void)hipFree(h->d_geom); (void)hipFree(h->d_mat);
-    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam); (void)hipFree(h->d_rgb8);
+    (void)hipFree(h->d_fx); (void)hipFree(h->d_accum); (void)hipFree(h->d_counters); (void)hipFree(h->d_cam); (void)hipFree(h->d_rgb8); (void)hipFree(h->d_ut);
     (void)hipFree(h->d_cell_start); (void)hipFree(h->d_items); (void)hipFree(h->d_item_ids);
     (void)hipFree(h->d_big_ids); (void)hipFree(h->d_big_local); (void)hipFree(h->d_big_scan); (void)hipFree(h->d_grid_shape);
     (void)hipStreamDestroy(h->own_stream);
@@ -1476,9 +1479,28 @@ int pt_reduce_stats(int* comm_inits, int* cached_ranks) {
 }
 
 // ---- unit-test entry points ----
+// Start of a unit-test call: room for `bytes` in the arena (the previous call ended with a stream synchronise).
+static int arena_begin(pt_handle h, size_t bytes) {
+    if (bytes > h->ut_cap) {
+        if (h->d_ut) { PT_HIP(h, hipFree(h->d_ut)); h->d_ut = nullptr; h->ut_cap = 0; }
+        const size_t cap = std::max<size_t>(bytes, 1 << 16);
+        PT_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->d_ut), cap));
+        h->ut_cap = cap;
+    }
+    h->ut_used = 0;
+    return 0;
+}
+static int arena_take(pt_handle h, DevBuf& b, size_t bytes) {
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (h->ut_used + need > h->ut_cap) return fail(h, PT_ERR_STATE, "unit-test arena too small (internal)");
+    b.p = h->d_ut + h->ut_used;
+    h->ut_used += need;
+    return 0;
+}
+#define PT_ARENA(bytes_per_element, buffers) do { if (int rc = arena_begin(h, size_t(n) * (bytes_per_element) + (buffers) * 256)) return rc; } while (0)
 #define PT_ALLOC_COPY(buf, ptr, bytes)                                                              \
     do {                                                                                            \
-        PT_HIP(h, buf.alloc(bytes));                                                                \
+        if (int rc = arena_take(h, buf, bytes)) return rc;                                          \
         if (ptr) PT_HIP(h, hipMemcpyAsync(buf.p, ptr, bytes, hipMemcpyHostToDevice, h->stream));    \
     } while (0)
 #define PT_COPY_BACK(ptr, buf, bytes) PT_HIP(h, hipMemcpyAsync(ptr, buf.p, bytes, hipMemcpyDeviceToHost, h->stream))
@@ -1491,6 +1513,7 @@ int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, 
     if (n == 0) return 0;
     PT_HIP(h, hipSetDevice(h->device));
     DevBuf bo, bd, bt, bi, bp, bn, bf;
+    PT_ARENA(4 * 24 + 8 + 4 + 4, 7);
     const size_t v3 = size_t(n) * 3 * sizeof(double);
     PT_ALLOC_COPY(bo, o, v3); PT_ALLOC_COPY(bd, d, v3);
     PT_ALLOC_COPY(bt, (void*)nullptr, n * sizeof(double)); PT_ALLOC_COPY(bi, (void*)nullptr, n * sizeof(int));
@@ -1527,6 +1550,7 @@ int pt_scatter(pt_handle h, int n, const int* kind, const double* albedo, const 
     for (int i = 0; i < n; ++i) if (kind[i] < 0 || kind[i] > 2) return fail(h, PT_ERR_INVALID, "pt_scatter: unknown material kind");
     PT_HIP(h, hipSetDevice(h->device));
     DevBuf bk, ba, bfz, bio, bd, bn, bfr, bu, bdo, bat, bok;
+    PT_ARENA(6 * 24 + 2 * 8 + 3 * 4, 11);
     const size_t v3 = size_t(n) * 3 * sizeof(double), s1 = size_t(n) * sizeof(double), i1 = size_t(n) * sizeof(int);
     PT_ALLOC_COPY(bk, kind, i1); PT_ALLOC_COPY(ba, albedo, v3); PT_ALLOC_COPY(bfz, fuzz, s1); PT_ALLOC_COPY(bio, ior, s1);
     PT_ALLOC_COPY(bd, d_in, v3); PT_ALLOC_COPY(bn, nrm, v3); PT_ALLOC_COPY(bfr, front, i1); PT_ALLOC_COPY(bu, u, v3);
@@ -1549,6 +1573,7 @@ int pt_gen_ray(pt_handle h, int n, int width, int height, const int* pi, const i
     if (n == 0) return 0;
     PT_HIP(h, hipSetDevice(h->device));
     DevBuf bi, bj, b1, b2, bx, by, bo, bd;
+    PT_ARENA(2 * 24 + 4 * 8 + 2 * 4, 8);
     const size_t v3 = size_t(n) * 3 * sizeof(double), s1 = size_t(n) * sizeof(double), i1 = size_t(n) * sizeof(int);
     PT_ALLOC_COPY(bi, pi, i1); PT_ALLOC_COPY(bj, pj, i1); PT_ALLOC_COPY(b1, u1, s1); PT_ALLOC_COPY(b2, u2, s1);
     PT_ALLOC_COPY(bx, diskx, s1); PT_ALLOC_COPY(by, disky, s1);
@@ -1568,6 +1593,7 @@ int pt_sky(pt_handle h, int n, const double* d, double* rgb) {
     if (n == 0) return 0;
     PT_HIP(h, hipSetDevice(h->device));
     DevBuf bd, bc;
+    PT_ARENA(2 * 24, 2);
     const size_t v3 = size_t(n) * 3 * sizeof(double);
     PT_ALLOC_COPY(bd, d, v3); PT_ALLOC_COPY(bc, (void*)nullptr, v3);
     hipLaunchKernelGGL(k_sky, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, bd.as<double>(), bc.as<double>());
@@ -1583,6 +1609,7 @@ int pt_philox(pt_handle h, int n, const uint32_t* ctr, const uint32_t key[2], ui
     if (n == 0) return 0;
     PT_HIP(h, hipSetDevice(h->device));
     DevBuf bc, bo;
+    PT_ARENA(2 * 16, 2);
     const size_t b = size_t(n) * 4 * sizeof(uint32_t);
     PT_ALLOC_COPY(bc, ctr, b); PT_ALLOC_COPY(bo, (void*)nullptr, b);
     hipLaunchKernelGGL(k_philox, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, bc.as<uint32_t>(), key[0], key[1], bo.as<uint32_t>());
