@@ -34,7 +34,12 @@ using namespace ptd;
 // =============================================================================================
 // Device side
 // =============================================================================================
-#define PT_COUNTER_WORDS 8
+// RenderParams::counters in u64 words: [0] rays of the call, [3] rays since the handle was made (the handle's own block
+// only), [8 + 16 k] job counter k of PT_JOB_COUNTERS (one cache line each), then the hand-over slots.
+#ifndef PT_JOB_COUNTERS
+#define PT_JOB_COUNTERS 2           // a power of two (measured: 2, 4 and 8 serve the 400x225 frame alike, 2 costs configs[1] least)
+#endif
+#define PT_COUNTER_WORDS (8 + 16 * PT_JOB_COUNTERS)
 struct TailPath {                    // a path handed from k_render to k_tail: the ray it is about to trace and what it carries
     float o[3], dh[3], thr[3];
     float len, self_t;
@@ -67,7 +72,7 @@ struct RenderParams {
     int n_tail_slots;                // k_tail only: slots written by the k_render launch before it
 };
 PT_DEV unsigned long long* ray_counter(const RenderParams& P) { return P.counters; }
-PT_DEV unsigned int* job_counter(const RenderParams& P) { return reinterpret_cast<unsigned int*>(P.counters + 1); }
+PT_DEV unsigned int* job_counter(const RenderParams& P, unsigned k) { return reinterpret_cast<unsigned int*>(P.counters + 8 + 16 * k); }
 PT_DEV TailPath* tail_slots(const RenderParams& P) { return reinterpret_cast<TailPath*>(P.counters + PT_COUNTER_WORDS); }
 
 // A CameraDev from its 19 floats in device memory; the constant address space makes hipcc use scalar loads
@@ -166,7 +171,8 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 #endif
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[lane + 64 * i] = 0;
-    if (lane == 0) wave_number = blockIdx.x;
+    __shared__ unsigned int my_counter;             // the job counter this wave asks first (it moves on when that one has run out)
+    if (lane == 0) { wave_number = blockIdx.x; my_counter = blockIdx.x % PT_JOB_COUNTERS; }
 
     // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining
     int parity = 0;
@@ -276,7 +282,19 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 // out the rest. Thousands of waves asking one address at the same moment would queue for ~0.1 ms.
                 int job = int(blockIdx.x);
                 if (c_valid) {
-                    if (lane == 0) job = int(atomicAdd(job_counter(P), 1u));
+                    // Counter k hands out the jobs k, k + K, k + 2 K, ... (K counters on lines of their own: one address serves
+                    // about 88 requests per microsecond, too few for one-sample jobs at the end of a small frame). A wave
+                    // stays with the counter of its number until that one runs out, then moves to the next; no job is
+                    // left when all K have been asked in vain.
+                    if (lane == 0) {
+                        unsigned k = my_counter;
+                        for (int tries = 0; tries < PT_JOB_COUNTERS; ++tries) {
+                            job = int(atomicAdd(job_counter(P, k), 1u) * PT_JOB_COUNTERS + k);
+                            if (job < P.n_jobs) break;
+                            k = (k + 1) % PT_JOB_COUNTERS;
+                        }
+                        my_counter = k;
+                    }
                     job = __builtin_amdgcn_readfirstlane(job);
                 }
                 if (job >= P.n_jobs) {
@@ -713,7 +731,7 @@ struct pt_context {
     std::vector<hipEvent_t> ev;                 // pairs
     size_t ev_used = 0;
     int target_jobs = 262144;
-    int min_chunk = 4;                          // PT_MIN_CHUNK: fewest samples per pixel in a job
+    int min_chunk = 3;                          // PT_MIN_CHUNK: fewest samples per pixel in a job
     int tail_rounds = 1;                        // PT_TAIL_ROUNDS: workgroups of k_tail, in units of what the chip holds at a time
     int fine_chunk = 2;                         // PT_FINE_CHUNK: samples per pixel in the small jobs at the end of a launch (0: none)
     int fine_share_pct = 100;                   // PT_FINE_SHARE: their share, in percent of one large job per wave
@@ -1152,7 +1170,7 @@ int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* a
 static int render_core(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed, float* out,
                        unsigned long long* fx, unsigned long long* counters, size_t tail_cap, bool timed) {
     const size_t n_elems = size_t(width) * height * 3;
-    PT_HIP(h, hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    PT_HIP(h, hipMemsetAsync(counters, 0, sizeof(unsigned long long), h->stream));
     const int spp = spp_end - spp_begin;
     if (spp > 0 && max_depth > 0) {          // depth 0: calcColour returns black before it traces anything (Path Tracer.cpp:86)
         RenderParams P;
@@ -1200,8 +1218,14 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         const bool flat = use_grid && h->grid_info[1] == 1 && h->grid_flat_ok;       // one layer of cells: the walk without a y axis
         long long grid = std::min<long long>(jobs, (long long)resident * h->grid_factor_pct / 100);
         if (!use_grid) grid = std::min<long long>(grid, (long long)(tail_cap / PT_TAIL_PATHS));      // every wave may queue PT_TAIL_PATHS paths
-        // a wave's first job is its own number: the counter starts behind them
-        PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 1), int(grid < 1 ? 1 : grid), 1, h->stream));
+        if (grid < 1) grid = 1;
+        if (grid > PT_JOB_COUNTERS) grid -= grid % PT_JOB_COUNTERS;
+        // a wave's first job is its own number: counter k (jobs k, k + K, ...) starts behind the jobs the waves took that way
+        {
+            const int each = int(grid / PT_JOB_COUNTERS), more = int(grid % PT_JOB_COUNTERS);     // `more` only for launches of fewer than K waves
+            PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 8), each, 32 * PT_JOB_COUNTERS, h->stream));
+            if (more) PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 8), each + 1, 32 * more, h->stream));
+        }
         timed = timed && h->ev_used + 2 <= 8192;
         if (timed && h->ev.size() < h->ev_used + 2) {
             hipEvent_t a, b;
