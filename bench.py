@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--spheres", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the grid-search and 10k-sphere lines (N=1 only)")
+    ap.add_argument("--launch-timeout", type=float, default=None,
+                    help="seconds the parent waits for its ranks before it terminates them (default PT_BENCH_TIMEOUT or 1500)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control flow on ONE device: every rank renders on cuda:0 and the reduce goes "
                          "through gloo on host copies (RCCL refuses two ranks on one GPU); not a measurement")
@@ -91,32 +93,103 @@ def _free_port():
     return port
 
 
-def spawn_ranks(n, argv):
+def _tail(path, n_bytes=3000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            size = f.tell()
+            f.seek(max(0, size - n_bytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def spawn_ranks(n, argv, timeout_s=None):
     """Starts n fresh copies of this script, one rank each, and relays rank 0's output. A process that has used
-    the GPU is never replaced or re-executed: the parent only waits."""
+    the GPU is never replaced or re-executed: the parent only watches its children.
+
+    Fail-fast: ALL children are polled. The moment one exits non-zero (a bad device index, an RCCL set-up error) the
+    others would wait in the rendezvous or in a collective for the backend's multi-minute timeout, so they are
+    terminated (exactly the children started here, by PID), the failed rank is named with the tail of its stderr and
+    its exit code is returned. The whole launch has a time limit (--launch-timeout / PT_BENCH_TIMEOUT, seconds)."""
+    import tempfile
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("PT_BENCH_TIMEOUT", "1500"))
     port = _free_port()
-    procs = []
+    tmp = tempfile.mkdtemp(prefix="pt_bench_")
+    procs, logs = [], []
     for rank in range(n):
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PT_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                                             # the exact child started above
-            p.wait()
-        rc = rc or p.returncode
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in env and not os.environ.get("PT_BENCH_KEEP_ENV"):
+            # The pool's image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (its host driver only does dmabuf IPC; without it
+            # RCCL between processes fails with `hipIpcGetMemHandle: invalid argument`, per the pool's documentation),
+            # so on the pool this branch does not run. Elsewhere the variable is added and SAID so; PT_BENCH_KEEP_ENV=1
+            # leaves the environment alone. DESIGN.md section 4.
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+            if rank == 0:
+                print("bench.py: HSA_ENABLE_IPC_MODE_LEGACY was not set; children get =0 (PT_BENCH_KEEP_ENV=1 to leave it unset)",
+                      file=sys.stderr, flush=True)
+        so = open(os.path.join(tmp, "rank%d.out" % rank), "wb")
+        se = open(os.path.join(tmp, "rank%d.err" % rank), "wb")
+        logs.append((so, se))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=so, stderr=se))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                                    # the exact children started above
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t_start = last_note = time.time()
+    rc, failed = 0, None
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(states) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0]
+            stop_all()
+            break
+        if all(c == 0 for c in states):
+            break
+        if time.time() - t_start > timeout_s:
+            running = [r for r, c in enumerate(states) if c is None]
+            print("bench.py: launch timed out after %.0f s; ranks still running: %s" % (timeout_s, running), file=sys.stderr, flush=True)
+            failed, rc = running[0], 124
+            stop_all()
+            break
+        if time.time() - last_note > 60:
+            last_note = time.time()
+            print("bench.py: %d ranks running, %.0f s" % (n, last_note - t_start), file=sys.stderr, flush=True)
+        time.sleep(0.05)
+    for so, se in logs:
+        so.close()
+        se.close()
+    # rank 0's stderr is relayed whole (warnings of the libraries); a failed rank's tail is shown with its number
+    sys.stderr.write(_tail(os.path.join(tmp, "rank0.err"), 1 << 20))
+    if failed is not None:
+        print("bench.py: rank %d of %d exited with code %d after %.1f s; the other ranks were terminated. Its stderr ends:\n%s"
+              % (failed, n, rc, time.time() - t_start, _tail(os.path.join(tmp, "rank%d.err" % failed))), file=sys.stderr, flush=True)
     # rank 0's JSON line goes to stdout; anything else a library printed there (gloo's connection notes) to stderr
+    try:
+        with open(os.path.join(tmp, "rank0.out"), "rb") as f:
+            out = f.read()
+    except OSError:
+        out = b""
     for line in out.decode(errors="replace").splitlines():
         is_json = line.startswith("{") and line.rstrip().endswith("}")
+        if is_json and failed is not None:
+            continue                                             # a failed launch reports nothing as a result
         print(line, file=sys.stdout if is_json else sys.stderr, flush=True)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return rc
 
 
@@ -183,6 +256,32 @@ def measured_traffic(default_workload):
     return None, None
 
 
+def n1_record(args, ms_per_step=None):
+    """The 1-GPU step time of the same workload arguments, for `scaling_efficiency_vs`: PT_BENCH_N1_MS when given, else what
+    an earlier `--gpus 1` run of the same arguments on this machine left in the temporary directory. With ms_per_step
+    (a 1-GPU run) the record is written."""
+    import tempfile
+    key = "%s_%dx%d_%dspp_d%d_%dsph_%s" % (args.workload, args.width, args.height, args.spp, args.depth, args.spheres, args.scaling)
+    path = os.path.join(tempfile.gettempdir(), "pt_bench_n1_%s.json" % key)
+    if ms_per_step is not None:
+        try:
+            with open(path, "w") as f:
+                json.dump({"ms_per_step": ms_per_step, "time": time.time()}, f)
+        except OSError:
+            pass
+        return None
+    if os.environ.get("PT_BENCH_N1_MS"):
+        try:
+            return {"ms_per_step": float(os.environ["PT_BENCH_N1_MS"]), "source": "PT_BENCH_N1_MS"}
+        except ValueError:
+            return None
+    try:
+        with open(path) as f:
+            return {"ms_per_step": float(json.load(f)["ms_per_step"]), "source": path}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def extras(dev, host, accum, W, H, spp, depth, scene, cam):
     """Outside the timed region and outside the roofline figure: the same workload with the optional grid search
     (pt_set_accel), configs[4] (10k spheres, 256 spp) once with each search, the reference's
@@ -237,7 +336,13 @@ def extras(dev, host, accum, W, H, spp, depth, scene, cam):
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+    # fault injection for tests/test_bench_launch.py: the named rank dies before it joins the rendezvous
+    if os.environ.get("PT_BENCH_FAIL_RANK") == os.environ.get("RANK", "0") and os.environ.get("PT_BENCH_CHILD"):
+        print("bench.py: PT_BENCH_FAIL_RANK: rank %s exits with code 3 on purpose" % os.environ.get("RANK"), file=sys.stderr, flush=True)
+        sys.exit(3)
+    if os.environ.get("PT_BENCH_HANG_RANK") == os.environ.get("RANK", "0") and os.environ.get("PT_BENCH_CHILD"):
+        time.sleep(3600)                          # fault injection: a rank that never reaches the rendezvous
 
     import numpy as np
     import torch
@@ -272,6 +377,7 @@ def main():
         spp_begin, spp_end = ptd.split_range(spp, world, rank)  # the frame's `spp` cut into `world` ranges
         frame_spp = spp
 
+    reduce_marks = []                                # per step: (event, event) around the reduce, or seconds on the host path
     if no_gpu:
         dev = None
         n_spheres = args.spheres + 5
@@ -279,7 +385,9 @@ def main():
 
         def step():
             accum.zero_()
+            t_r = time.perf_counter()
             ptd.reduce_frame(accum, dst=0)
+            reduce_marks.append(time.perf_counter() - t_r)
 
         def fence():
             if world > 1:
@@ -298,12 +406,23 @@ def main():
         def step():
             accum.zero_()
             dev.render(W, H, spp_begin, spp_end, depth, 42, accum_ptr=accum.data_ptr())
-            if host_reduce and world > 1:
+            if world == 1:
+                return
+            if host_reduce:
+                t_r = time.perf_counter()
                 host_copy = accum.cpu()
                 ptd.reduce_frame(host_copy, dst=0)
                 accum.copy_(host_copy)
+                reduce_marks.append(time.perf_counter() - t_r)
             else:
+                # Events on torch's current stream, the stream the kernels run on (set_stream above). dist.reduce runs on
+                # RCCL's own stream, which first waits for this one and which this one then waits for, so the pair brackets
+                # "wait for the slowest rank + the transfer" as this rank sees it.
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 ptd.reduce_frame(accum, dst=0)
+                e1.record()
+                reduce_marks.append((e0, e1))
 
         def fence():
             torch.cuda.synchronize()
@@ -318,6 +437,7 @@ def main():
     if dev:
         dev.kernel_times()                       # drop the warm-up records
         rays0 = dev.ray_count()
+    del reduce_marks[:]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -327,14 +447,38 @@ def main():
     rays = dev.ray_count() - rays0 if dev else 0
     ktimes = dev.kernel_times() if dev else []
 
+    phases = None
     if world > 1:
         stat_dev = "cpu" if host_reduce else "cuda"
+        own_dt = dt
         t = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         r = torch.tensor([rays], dtype=torch.int64, device=stat_dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         total_rays = int(r.item())
+        # where each rank's step went: its sample-loop kernels, its reduce (wait for the slowest rank + transfer), its wall time
+        if reduce_marks and not isinstance(reduce_marks[0], float):
+            red = [a.elapsed_time(b) for a, b in reduce_marks]
+        else:
+            red = [1e3 * v for v in reduce_marks]
+        mine = torch.tensor([float(np.mean(ktimes)) if len(ktimes) else float("nan"),
+                             float(np.max(ktimes)) if len(ktimes) else float("nan"),
+                             float(np.mean(red)) if red else float("nan"),
+                             own_dt / args.steps * 1e3, float(rays)], dtype=torch.float64, device=stat_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        tab = np.array([e.cpu().numpy() for e in every])
+        phases = {"kernel_ms_per_rank": [float(v) for v in tab[:, 0]],
+                  "kernel_ms_max_per_rank": [float(v) for v in tab[:, 1]],
+                  "reduce_ms_per_rank": [float(v) for v in tab[:, 2]],
+                  "step_ms_per_rank": [float(v) for v in tab[:, 3]],
+                  "rays_per_rank": [int(v) for v in tab[:, 4]],
+                  "reduce_ms": float(tab[0, 2]),
+                  "max_rank_skew_ms": float(np.nanmax(tab[:, 0]) - np.nanmin(tab[:, 0])),
+                  "note": "means over the timed steps; kernel = k_render + k_tail (HIP events in the library); reduce = events on "
+                          "the kernels' stream around dist.reduce (host path: wall clock incl. the copies), i.e. waiting for the "
+                          "slowest rank plus the transfer; reduce_ms is rank 0's (the root); skew = max - min kernel_ms over ranks"}
     else:
         total_rays = rays
 
@@ -375,6 +519,15 @@ def main():
                          "flops_per_launch": flops_per_launch,
                          "note": "algorithmic flops = rays x (17 x spheres + 60); rays counted by the kernel"},
         }
+        if phases:
+            out["phases"] = phases
+        n1 = n1_record(args, out["ms_per_step"] if world == 1 and not no_gpu else None)
+        if world > 1 and n1:
+            ideal = n1["ms_per_step"] if args.scaling == "weak" else n1["ms_per_step"] / world
+            out["scaling_efficiency_vs"] = {"n1_ms_per_step": n1["ms_per_step"], "source": n1["source"],
+                                            "efficiency": ideal / out["ms_per_step"],
+                                            "note": "ideal step = the 1-GPU step of the same arguments (weak) or that / N (strong); "
+                                                    "the driver computes its own from the per-N lines"}
         if args.scaling == "weak":
             out["config"]["spp_per_gpu"] = spp
         else:

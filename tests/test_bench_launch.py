@@ -38,6 +38,48 @@ def test_bench_spawns_its_own_ranks():
     assert out["ms_per_step"] > 0
 
 
+def test_phases_and_efficiency_fields_of_a_two_rank_line():
+    env = _clean_env()
+    env["PT_BENCH_N1_MS"] = "1000"
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = _one_json_line(p.stdout)
+    ph = out["phases"]
+    for k in ("kernel_ms_per_rank", "reduce_ms_per_rank", "step_ms_per_rank", "rays_per_rank"):
+        assert len(ph[k]) == 2, k
+    assert ph["reduce_ms"] == ph["reduce_ms_per_rank"][0] and ph["reduce_ms"] > 0 and "max_rank_skew_ms" in ph
+    assert all(abs(v - out["ms_per_step"]) < 0.5 * out["ms_per_step"] + 5 for v in ph["step_ms_per_rank"])
+    eff = out["scaling_efficiency_vs"]
+    assert eff["source"] == "PT_BENCH_N1_MS" and abs(eff["efficiency"] - 1000.0 / out["ms_per_step"]) < 1e-6   # weak: ideal = the 1-GPU step
+
+
+def test_a_rank_that_dies_at_start_ends_the_launch_quickly():
+    """Rank 1 exits with code 3 before the rendezvous: rank 0 would wait in init_process_group for minutes. The parent
+    must notice, terminate rank 0, name the failed rank and return non-zero, in well under the backend's timeout."""
+    import time
+    env = _clean_env()
+    env["PT_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    took = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr.decode()[-2000:])
+    assert took < 30, took
+    err = p.stderr.decode()
+    assert "rank 1 of 2 exited with code 3" in err and "PT_BENCH_FAIL_RANK" in err
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]      # no result line from a failed launch
+
+
+def test_launch_timeout_terminates_the_ranks():
+    import time
+    env = _clean_env()
+    env["PT_BENCH_HANG_RANK"] = "0"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-timeout", "8"] + SMALL, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 124 and time.time() - t0 < 40, (p.returncode, p.stderr.decode()[-2000:])
+    assert b"launch timed out" in p.stderr
+
+
 def test_bench_under_an_outside_launcher():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
