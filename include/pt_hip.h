@@ -41,6 +41,18 @@ enum {
     PT_ERR_RCCL = 4       /* an RCCL call failed */
 };
 
+/* Tuning variables, read from the environment ONCE, in pt_create (a handle keeps what it read). None changes a result:
+ * the sums are integers, a frame is bit-identical for any job shape (tests/test_gpu_parity.py renders one frame under six
+ * settings). Defaults are what the committed measurements used; they exist for the A/B runs of tools/.
+ *   PT_TARGET_JOBS   (262144) jobs a frame is cut into at least (job = 8x8 pixel tile x a chunk of samples)
+ *   PT_MIN_CHUNK     (3)      fewest samples per pixel in a job
+ *   PT_FINE_CHUNK    (2)      samples per pixel of the small jobs handed out last (0: none)
+ *   PT_FINE_SHARE    (100)    their total, in percent of one large job per resident wave
+ *   PT_TAIL_ROUNDS   (1)      workgroups of the end-of-frame kernel, in units of what the chip holds at once
+ *   PT_GRID_PCT      (100)    persistent grid size in percent of the resident waves
+ *   PT_GRID_CELL_SCALE (4.0), PT_GRID_BIG_RATIO (3.0), PT_GRID_FLAT (1)   shape of the optional grid search (pt_set_accel)
+ * A production host that must not depend on the environment clears these variables before pt_create. */
+
 /* One context per GPU. Replaces the construction of dp::thread_pool (Path Tracer.cpp:286,
  * ThreadPool.h:132-144): the pool of hardware_concurrency() workers becomes one device. */
 int pt_create(int device_index, pt_handle* out);
@@ -132,6 +144,10 @@ int pt_ray_count(pt_handle h, uint64_t* out);
  * to this function, measured with HIP events on the stream the kernel ran on. Synchronises.
  * Writes at most cap values and the number of renders recorded into *n. */
 int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n);
+/* The same records with the part spent in the end-of-frame kernel (k_tail, launched behind the sample-loop kernel to
+ * finish the few long paths its waves were left with; 0 for the grid search) in tail_ms (may be NULL): out_ms[i] is the
+ * whole, out_ms[i] - tail_ms[i] the sample-loop kernel alone. Like pt_kernel_times it clears the records. */
+int pt_kernel_times_split(pt_handle h, float* out_ms, float* tail_ms, int cap, int* n);
 
 /* Sum the own accumulation buffers of n handles (one per GPU of this process) into handles[root]
  * with an RCCL reduce. No counterpart in the reference, which shares one vector between threads
@@ -149,6 +165,15 @@ int pt_reduce_stats(int* comm_inits, int* cached_ranks);
  * |d| like the reference's; idx is the list index or -1. p, nrm are [n][3]. */
 int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, double* t, int* idx, double* p,
             double* nrm, int* front);
+
+/* calcColour (Path Tracer.cpp:82-108) for n given rays, with the uniform numbers of every scatter injected instead of
+ * drawn: the loop of pt_render (closest hit -> sky on a miss, Path Tracer.cpp:105-107 | hit record, depth rule :86,
+ * Material::isScattered :96, product of attenuations :97, refused scatter -> black :100) on the same device functions,
+ * without philox, regeneration and sums, so that whole paths can be pinned by hand-derived vectors. o, d are [n][3]
+ * (d un-normalised, like the reference's rays); u is [n][max_depth][3]: the scatter at the k-th hit of path i takes
+ * u[i][k] = (u1, u2 for the sphere point, VectorFunc.cpp:40-41; u3 for the Fresnel coin, Dielectric.cpp:27).
+ * rgb is [n][3]; n_rays[i] = rays traced for path i (calcColour entries with depth > 0). max_depth = 0: black, 0 rays. */
+int pt_trace(pt_handle h, int n, const double* o, const double* d, int max_depth, const double* u, double* rgb, int* n_rays);
 
 /* Material::isScattered with the uniform numbers injected (Lambertian.cpp:5-16, Metal.cpp:6-15,
  * Dielectric.cpp:5-50, VectorFunc.cpp:37-43, :66-76). albedo, d_in, p, nrm, u, d_out, atten are [n][3];

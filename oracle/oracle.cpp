@@ -306,7 +306,9 @@ static bool scatter(const SphereRec& m, const Ray& in, const Hit& h, double u1, 
 struct Sampler {
     // mode 0: the reference's three Mersenne Twisters (faithful draw order and counts).
     // mode 1: one philox4x32-10 block per (pixel, sample, bounce), the GPU's numbering.
+    // mode 2: injected: the scatter at the k-th hit of the path takes (u1, u2, u3) = inject[3 k .. 3 k + 2] (orc_trace).
     int mode = 0;
+    const double* inject = nullptr;
     MT19937* a = nullptr;            // RNG-A, Path Tracer.cpp:48-52 (thread_local in the reference)
     MT19937* b = nullptr;            // RNG-B, VectorFunc.cpp:15-19
     MT19937* c = nullptr;            // RNG-C, Dielectric.cpp:52-56
@@ -337,6 +339,8 @@ static V3 radiance(const Scene& sc, const Ray& r, int depth, int ray_index, Samp
                 u2 = sm.b->uniform(0.0, 1.0);                            // :41
             }
             if (sm.lock) sm.lock->unlock();
+        } else if (sm.mode == 2) {
+            u1 = sm.inject[3 * ray_index]; u2 = sm.inject[3 * ray_index + 1]; u3 = sm.inject[3 * ray_index + 2];
         } else {
             sm.block(uint32_t(ray_index) + 1);
             u1 = u24(sm.blk[0]); u2 = u24(sm.blk[1]); u3 = u24(sm.blk[2]);
@@ -493,6 +497,23 @@ void orc_sky(int n, const double* d, double* rgb) {
         V3 ud = unit({d[3 * k], d[3 * k + 1], d[3 * k + 2]});
         double t = 0.5 * (ud.y + 1);
         rgb[3 * k] = (1.0 - t) + 0.5 * t; rgb[3 * k + 1] = (1.0 - t) + 0.7 * t; rgb[3 * k + 2] = (1.0 - t) + 1.0 * t;
+    }
+}
+
+// calcColour (Path Tracer.cpp:82-108) for given rays with the uniform numbers of every scatter injected: u is
+// [n][max_depth][3], the scatter at the k-th hit of path i takes u[i][k] = (u1, u2 for the sphere point, u3 for the
+// Fresnel coin). rgb is [n][3]; n_rays[i] = calcColour entries with depth > 0 (rays traced) of path i.
+void orc_trace(void* scene, int n, const double* o, const double* d, int max_depth, const double* u, double* rgb, int* n_rays) {
+    const Scene& sc = *static_cast<Scene*>(scene);
+    for (int k = 0; k < n; ++k) {
+        Ray r{{o[3 * k], o[3 * k + 1], o[3 * k + 2]}, {d[3 * k], d[3 * k + 1], d[3 * k + 2]}};
+        Sampler sm;
+        sm.mode = 2;
+        sm.inject = u + size_t(k) * size_t(max_depth > 0 ? max_depth : 0) * 3;
+        uint64_t rays = 0;
+        V3 c = radiance(sc, r, max_depth, 0, sm, rays);
+        rgb[3 * k] = c.x; rgb[3 * k + 1] = c.y; rgb[3 * k + 2] = c.z;
+        n_rays[k] = int(rays);
     }
 }
 

@@ -36,9 +36,11 @@ SIGNATURES = {
     "pt_quantise_rgb8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_uint8)]),
     "pt_ray_count": (C.c_int, [C.c_void_p, _u64p]),
     "pt_kernel_times": (C.c_int, [C.c_void_p, _fp, C.c_int, _ip]),
+    "pt_kernel_times_split": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _ip]),
     "pt_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "pt_reduce_stats": (C.c_int, [_ip, _ip]),
     "pt_scan": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_double, _dp, _ip, _dp, _dp, _ip]),
+    "pt_trace": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _ip]),
     "pt_scatter": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _ip]),
     "pt_gen_ray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp]),
     "pt_sky": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
@@ -196,6 +198,15 @@ class Device:
         self._ck(self.lib.pt_kernel_times(self.h, _p(out, _fp), cap, C.byref(n)), "pt_kernel_times")
         return out[:min(n.value, cap)].copy()
 
+    def kernel_times_split(self, cap=4096):
+        """(whole, tail) kernel milliseconds per render since the last call: whole = k_render + k_tail, tail = k_tail alone."""
+        out = np.zeros(cap, dtype=np.float32)
+        tail = np.zeros(cap, dtype=np.float32)
+        n = C.c_int(0)
+        self._ck(self.lib.pt_kernel_times_split(self.h, _p(out, _fp), _p(tail, _fp), cap, C.byref(n)), "pt_kernel_times_split")
+        k = min(n.value, cap)
+        return out[:k].copy(), tail[:k].copy()
+
     # -- unit-test entry points ----------------------------------------------------------------
     def scan(self, o, d, t_min=0.001):
         o, d = _d(o), _d(d)
@@ -208,6 +219,17 @@ class Device:
         self._ck(self.lib.pt_scan(self.h, n, _p(o, _dp), _p(d, _dp), t_min, _p(t, _dp), _p(idx, _ip), _p(p, _dp),
                                   _p(nrm, _dp), _p(front, _ip)), "pt_scan")
         return dict(t=t, idx=idx, p=p, n=nrm, front=front)
+
+    def trace(self, o, d, max_depth, u):
+        """calcColour for given rays with the uniforms of every scatter injected: u is [n][max_depth][3]."""
+        o, d = _d(o), _d(d)
+        n = o.shape[0]
+        u = _d(np.asarray(u, dtype=np.float64).reshape(n, max(max_depth, 0), 3))
+        rgb = np.zeros((n, 3))
+        rays = np.zeros(n, dtype=np.int32)
+        self._ck(self.lib.pt_trace(self.h, n, _p(o, _dp), _p(d, _dp), max_depth, _p(u, _dp) if u.size else None, _p(rgb, _dp),
+                                   _p(rays, _ip)), "pt_trace")
+        return dict(rgb=rgb, rays=rays)
 
     def scatter(self, kind, albedo, fuzz, ior, d_in, p, nrm, front, u):
         kind, front = _i(kind), _i(front)

@@ -40,6 +40,7 @@ using namespace ptd;
 #define PT_JOB_COUNTERS 2           // a power of two (measured: 2, 4 and 8 serve the 400x225 frame alike, 2 costs configs[1] least)
 #endif
 #define PT_COUNTER_WORDS (8 + 16 * PT_JOB_COUNTERS)
+#define PT_MAX_SPP_CHUNK 65536      // samples per pixel in one job: 8 rows x 65,536 = 2^19 row-items, below the 2^20 of the reciprocal trick in k_render
 struct TailPath {                    // a path handed from k_render to k_tail: the ray it is about to trace and what it carries
     float o[3], dh[3], thr[3];
     float len, self_t;
@@ -64,10 +65,11 @@ struct RenderParams {
     SceneDev scene;
     GridDev grid;                    // read by k_render<1> and k_render<2> only
     unsigned long long* accum_fx;    // [3][H][W] fixed-point (2^-32) sums, top row first
-    // One block of device memory, 8 x u64 of counters and then the slots through which k_render<0> hands paths to
-    // k_tail (PT_TAIL_PATHS slots per wave of the launch): [0] rays of this call; [1] next job to hand out (u32; the
-    // launch sets it to the number of waves, whose first jobs are their own numbers). One pointer instead of three:
-    // the scan leaves no scalar register to spare.
+    // One block of device memory: PT_COUNTER_WORDS u64 of counters, then the slots through which k_render<0> hands paths
+    // to k_tail (PT_TAIL_PATHS slots per wave of the launch). Words: [0] rays of this call; [3] rays since the handle was
+    // made (the handle's own block only); [8 + 16 k] job counter k of PT_JOB_COUNTERS, a u32 on a cache line of its own
+    // (the launch sets it to the jobs its waves took as their first, whose numbers are the waves' own). One pointer
+    // instead of three: the scan leaves no scalar register to spare.
     unsigned long long* counters;
     int n_tail_slots;                // k_tail only: slots written by the k_render launch before it
 };
@@ -118,11 +120,7 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const unsigned long long v = bank[lane * 3 + c];
-#ifndef PT_EXP_NOFLUSH
             if (v) atomicAdd(dst + c * plane, v);
-#else
-            if (v == 1234567) atomicAdd(dst + c * plane, v);
-#endif
         }
     }
     unsigned long long zero = 0;
@@ -329,6 +327,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 if (c_vh != 8 || n_vh != 8) {                                        // wave-uniform: a tile of the bottom edge
                     const int vh = from_new ? n_vh : c_vh;
                     const int t = k >> 3;
+                    static_assert(8 * PT_MAX_SPP_CHUNK <= (1 << 20), "t = k >> 3 < vh * spp_chunk must stay below 2^20 for the reciprocal quotient");
                     smp = int((float(t) + 0.5f) * __builtin_amdgcn_rcpf(float(vh)));  // t / vh for vh <= 8, t < 2^20: the quotient is at least 1/16 from an integer
                     row = t - smp * vh;
                 }
@@ -618,6 +617,45 @@ __global__ void k_scan(SceneDev sc, GridDev grid, int n, const double* o, const 
     front[k] = h.front ? 1 : 0;
 }
 
+// calcColour (Path Tracer.cpp:82-108) for one given ray per thread with the uniform numbers of every scatter injected:
+// the loop body of k_render (scan -> sky | finish, depth rule, shade, next ray) without philox, regeneration and sums.
+// u is [n][max_depth][3]: the scatter at the k-th hit of a path takes u[k] = (u1, u2: sphere point; u3: Fresnel coin).
+template <int MODE>
+__global__ void k_trace(SceneDev sc, GridDev grid, int n, const double* o, const double* d, int max_depth, const double* u,
+                        double* rgb, int* n_rays) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    f3 ro = mk3(float(o[3 * k]), float(o[3 * k + 1]), float(o[3 * k + 2]));
+    float len;
+    f3 dh = normalise(mk3(float(d[3 * k]), float(d[3 * k + 1]), float(d[3 * k + 2])), len);
+    f3 thr = mk3(1, 1, 1), c = mk3(0, 0, 0);
+    float self_t = 0.0f;
+    int prev = -1, bounce = 0, rays = 0;
+    bool active = max_depth > 0;                                              // Path Tracer.cpp:86
+    while (active) {
+        ++rays;
+        float bt; int bi;
+        if constexpr (MODE == 0) scan_spheres(sc, ro, dh, 0.001f * len, prev, self_t, bt, bi);
+        else scan_grid<MODE == 2>(grid, ro, dh, 0.001f * len, prev, self_t, bt, bi);
+        if (bi < 0) { c = thr * sky(dh.y); break; }                           // :105-107
+        const HitRec h = finish_hit(sc, bi, bi == prev, ro, dh, 0.001 * double(len));
+        const MatRec mat = sc.mat[bi];
+        prev = bi;
+        ++bounce;
+        if (bounce >= max_depth) break;                                       // the next ray would enter with depth <= 0 (:86): black
+        const double* uu = u + (size_t(k) * size_t(max_depth) + size_t(bounce - 1)) * 3;
+        f3 dd, atten;
+        const bool ok = shade(mat, dh, len, h.n, h.front, float(uu[0]), float(uu[1]), float(uu[2]), dd, atten);
+        thr = thr * atten;                                                    // :97
+        ro = h.p;
+        dh = normalise(dd, len);
+        self_t = self_far_root(h.r, h.n, h.front, dh);
+        active = ok;                                                          // :100 -> black
+    }
+    rgb[3 * k] = c.x; rgb[3 * k + 1] = c.y; rgb[3 * k + 2] = c.z;
+    n_rays[k] = rays;
+}
+
 __global__ void k_scatter(int n, const int* kind, const double* albedo, const double* fuzz, const double* ior,
                           const double* d_in, const double* nrm, const int* front, const double* u, double* d_out,
                           double* atten, int* ok) {
@@ -723,7 +761,7 @@ struct pt_context {
     size_t ut_cap = 0, ut_used = 0;
     unsigned char* d_rgb8 = nullptr;            // output stage (pt_quantise_rgb8): kept between frames, grows only
     size_t rgb8_cap = 0;
-    unsigned long long* d_counters = nullptr;   // RenderParams::counters: 8 words ([3] = rays since creation) and the queue of k_tail
+    unsigned long long* d_counters = nullptr;   // RenderParams::counters: PT_COUNTER_WORDS words ([3] = rays since creation) and the slots of k_tail
     size_t tail_cap = 0;                        // capacity of that queue in entries
     int resident_waves = 0;                     // waves the device holds at once (persistent grid size)
     int n_cus = 256;
@@ -941,7 +979,8 @@ int pt_create(int device_index, pt_handle* out) {
     pt_context* h = new (std::nothrow) pt_context;
     if (!h) return fail(nullptr, PT_ERR_INVALID, "pt_create: out of host memory");
     h->device = device_index;
-    PT_HIP(nullptr, hipSetDevice(device_index));
+    e = hipSetDevice(device_index);
+    if (e != hipSuccess) { delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
     e = hipStreamCreate(&h->own_stream);
     if (e != hipSuccess) { delete h; return fail(nullptr, PT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     h->stream = h->own_stream;
@@ -1165,8 +1204,8 @@ int pt_quantise_rgb8(pt_handle h, int width, int height, int spp, const float* a
 
 // The sample loop of one call, shared by pt_render and pt_render_noalloc: clears the two call counters, launches
 // k_render on the handle's stream (sums into fx, which must be zero), then k_resolve (fx -> out, fx back to zero).
-// Allocates nothing unless `timed` needs a new pair of events. counters: RenderParams::counters (8 words, then the queue
-// of k_tail with room for tail_cap entries).
+// Allocates nothing unless `timed` needs new events. counters: RenderParams::counters (PT_COUNTER_WORDS words, then the
+// slots of k_tail with room for tail_cap entries).
 static int render_core(pt_handle h, int width, int height, int spp_begin, int spp_end, int max_depth, uint64_t seed, float* out,
                        unsigned long long* fx, unsigned long long* counters, size_t tail_cap, bool timed) {
     const size_t n_elems = size_t(width) * height * 3;
@@ -1184,6 +1223,10 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         const int min_chunk = h->min_chunk;
         if (want > (spp + min_chunk - 1) / min_chunk) want = (spp + min_chunk - 1) / min_chunk;     // at least min_chunk spp (x 64 items) per job
         P.spp_chunk = int((spp + want - 1) / want);
+        // A job's item number k = (sample, row, column) is an int below 64 * spp_chunk, and a bottom-edge tile divides
+        // k >> 3 by its row count with a reciprocal that is exact below 2^20 (k_render): bound the chunk (more, smaller
+        // jobs instead; reached only with more than 65,536 samples per pixel and tile in one call).
+        if (P.spp_chunk > PT_MAX_SPP_CHUNK) P.spp_chunk = PT_MAX_SPP_CHUNK;
         const bool use_grid = h->accel == PT_ACCEL_GRID;
         const int resident = use_grid ? h->resident_waves_grid : h->resident_waves;   // from pt_create
         // The last jobs are small ones: as many samples as one large job for every wave of the launch (a wave that took
@@ -1226,11 +1269,12 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
             PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 8), each, 32 * PT_JOB_COUNTERS, h->stream));
             if (more) PT_HIP(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(counters + 8), each + 1, 32 * more, h->stream));
         }
-        timed = timed && h->ev_used + 2 <= 8192;
-        if (timed && h->ev.size() < h->ev_used + 2) {
-            hipEvent_t a, b;
-            PT_HIP(h, hipEventCreate(&a)); PT_HIP(h, hipEventCreate(&b));
-            h->ev.push_back(a); h->ev.push_back(b);
+        // three events per timed call: before k_render, between k_render<0> and k_tail, after the last kernel
+        timed = timed && h->ev_used + 3 <= 3 * 4096;
+        while (timed && h->ev.size() < h->ev_used + 3) {
+            hipEvent_t a;
+            PT_HIP(h, hipEventCreate(&a));
+            h->ev.push_back(a);
         }
         if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used], h->stream));
         if (flat) hipLaunchKernelGGL(k_render<2>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
@@ -1238,6 +1282,7 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
         else {
             hipLaunchKernelGGL(k_render<0>, dim3(unsigned(grid < 1 ? 1 : grid)), dim3(64), 0, h->stream, P);
             PT_HIP(h, hipGetLastError());
+            if (timed) PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
             // the long paths the waves of k_render were left with (counted into the kernel time)
             P.n_tail_slots = int((grid < 1 ? 1 : grid) * PT_TAIL_PATHS);
             const size_t lds = size_t(P.scene.n_pad + 8) * 16 + size_t(P.scene.n) * (sizeof(GeomRec) + sizeof(MatRec));
@@ -1248,7 +1293,11 @@ static int render_core(pt_handle h, int width, int height, int spp_begin, int sp
             else hipLaunchKernelGGL(k_tail<false>, dim3(tail_blocks), dim3(256), 0, h->stream, P);
         }
         PT_HIP(h, hipGetLastError());
-        if (timed) { PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream)); h->ev_used += 2; }
+        if (timed) {
+            if (use_grid) PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));     // no k_tail behind the grid kernels
+            PT_HIP(h, hipEventRecord(h->ev[h->ev_used + 2], h->stream));
+            h->ev_used += 3;
+        }
     }
     {
         const size_t n_pixels = n_elems / 3;
@@ -1383,16 +1432,21 @@ int pt_ray_count(pt_handle h, uint64_t* out) {
     return 0;
 }
 
-int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n) {
+int pt_kernel_times_split(pt_handle h, float* out_ms, float* tail_ms, int cap, int* n) {
     if (!h || !n || (cap > 0 && !out_ms)) return PT_ERR_INVALID;
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipStreamSynchronize(h->stream));
-    const int count = int(h->ev_used / 2);
-    for (int i = 0; i < count && i < cap; ++i) PT_HIP(h, hipEventElapsedTime(&out_ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    const int count = int(h->ev_used / 3);
+    for (int i = 0; i < count && i < cap; ++i) {
+        PT_HIP(h, hipEventElapsedTime(&out_ms[i], h->ev[3 * i], h->ev[3 * i + 2]));
+        if (tail_ms) PT_HIP(h, hipEventElapsedTime(&tail_ms[i], h->ev[3 * i + 1], h->ev[3 * i + 2]));
+    }
     *n = count;
     h->ev_used = 0;
     return 0;
 }
+
+int pt_kernel_times(pt_handle h, float* out_ms, int cap, int* n) { return pt_kernel_times_split(h, out_ms, nullptr, cap, n); }
 
 // ---- RCCL reduce of the own accumulation buffers, single process, one handle per GPU ----
 // librccl is loaded once and the communicators are kept for the device list they were made for (set-up costs
@@ -1559,6 +1613,40 @@ int pt_scan(pt_handle h, int n, const double* o, const double* d, double t_min, 
     PT_HIP(h, hipGetLastError());
     PT_COPY_BACK(t, bt, n * sizeof(double)); PT_COPY_BACK(idx, bi, n * sizeof(int));
     PT_COPY_BACK(p, bp, v3); PT_COPY_BACK(nrm, bn, v3); PT_COPY_BACK(front, bf, n * sizeof(int));
+    PT_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pt_trace(pt_handle h, int n, const double* o, const double* d, int max_depth, const double* u, double* rgb, int* n_rays) {
+    if (!h) return PT_ERR_INVALID;
+    if (!h->have_scene) return fail(h, PT_ERR_STATE, "pt_trace: set the scene first");
+    if (n < 0 || max_depth < 0 || max_depth > 4096 || (n > 0 && (!o || !d || !rgb || !n_rays || (max_depth > 0 && !u))))
+        return fail(h, PT_ERR_INVALID, "pt_trace: bad arguments");
+    if (n == 0) return 0;
+    PT_HIP(h, hipSetDevice(h->device));
+    DevBuf bo, bd, bu, bc, br;
+    const size_t v3 = size_t(n) * 3 * sizeof(double), ub = std::max<size_t>(size_t(n) * size_t(max_depth) * 3 * sizeof(double), 8);
+    if (int rc = arena_begin(h, 3 * v3 + ub + size_t(n) * sizeof(int) + 5 * 256)) return rc;
+    PT_ALLOC_COPY(bo, o, v3); PT_ALLOC_COPY(bd, d, v3);
+    PT_ALLOC_COPY(bu, max_depth > 0 ? u : nullptr, ub);
+    PT_ALLOC_COPY(bc, (void*)nullptr, v3); PT_ALLOC_COPY(br, (void*)nullptr, n * sizeof(int));
+    const dim3 grid_dim((n + 63) / 64), block(64);
+    if (h->accel == PT_ACCEL_GRID) {
+        if (!h->grid_ready) return fail(h, PT_ERR_STATE, "pt_trace: the grid has not been built");
+        if (h->grid_info[1] == 1)
+            hipLaunchKernelGGL(k_trace<2>, grid_dim, block, 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(), max_depth,
+                               bu.as<double>(), bc.as<double>(), br.as<int>());
+        else
+            hipLaunchKernelGGL(k_trace<1>, grid_dim, block, 0, h->stream, scene_dev(h), h->grid, n, bo.as<double>(), bd.as<double>(), max_depth,
+                               bu.as<double>(), bc.as<double>(), br.as<int>());
+    } else {
+        GridDev none;
+        std::memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(k_trace<0>, grid_dim, block, 0, h->stream, scene_dev(h), none, n, bo.as<double>(), bd.as<double>(), max_depth,
+                           bu.as<double>(), bc.as<double>(), br.as<int>());
+    }
+    PT_HIP(h, hipGetLastError());
+    PT_COPY_BACK(rgb, bc, v3); PT_COPY_BACK(n_rays, br, n * sizeof(int));
     PT_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }

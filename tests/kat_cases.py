@@ -58,3 +58,36 @@ def first_random_sphere(kat):
     uniform = lambda c, lo, hi: c * (hi - lo) + lo                   # libstdc++ uniform_real_distribution::operator()
     return dict(selector=uniform(u[0], 0.0, 1.0), r=uniform(u[1], 0.1, 0.4), cx=uniform(u[2], -10.0, 10.0), cz=uniform(u[3], -10.0, 10.0),
                 albedo=[uniform(u[0], 0.0, 1.0), uniform(u[1], 0.0, 1.0), uniform(u[2], 0.0, 1.0)])
+
+
+def path_scene(case):
+    """The spheres of a whole-path case as the scene dict Device.set_scene / Oracle.scene_create take."""
+    sp = case["spheres"]
+    sc = {k: np.zeros(len(sp)) for k in ("cx", "cy", "cz", "r", "ar", "ag", "ab", "fuzz", "ior")}
+    sc["kind"] = np.zeros(len(sp), dtype=np.int32)
+    for i, s in enumerate(sp):
+        sc["cx"][i], sc["cy"][i], sc["cz"][i] = s["c"]
+        sc["r"][i] = s["r"]
+        sc["kind"][i] = s["kind"]
+        a = s.get("albedo", [1, 1, 1])
+        sc["ar"][i], sc["ag"][i], sc["ab"][i] = a
+        sc["fuzz"][i] = s.get("fuzz", 0.0)
+        sc["ior"][i] = s.get("ior", 0.0)
+    return sc
+
+
+def run_path_cases(trace_one, kat, atol):
+    """trace_one(scene dict, o[1][3], d[1][3], max_depth, u[1][max_depth][3]) -> dict(rgb=[1][3], rays=[1]).
+    Asserts colour and ray count of every hand-derived whole path (kat.json: whole_paths). Returns the largest deviation."""
+    worst = 0.0
+    for case in kat["whole_paths"]:
+        md = case["max_depth"]
+        u = np.zeros((1, max(md, 0), 3))
+        for k, v in enumerate(case["u"]):
+            u[0, k] = v
+        got = trace_one(path_scene(case), [case["o"]], [case["d"]], md, u)
+        err = float(np.abs(np.asarray(got["rgb"][0], dtype=np.float64) - np.array(case["rgb"], dtype=np.float64)).max())
+        assert err <= atol, (case["name"], got["rgb"][0], case["rgb"])
+        assert int(got["rays"][0]) == case["rays"], (case["name"], int(got["rays"][0]), case["rays"])
+        worst = max(worst, err)
+    return worst

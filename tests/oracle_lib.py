@@ -59,6 +59,7 @@ class Oracle:
         L.orc_scan.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, _dp, _ip, _dp, _dp, _ip]
         L.orc_scatter.argtypes = [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp, _ip]
         L.orc_sky.argtypes = [C.c_int, _dp, _dp]
+        L.orc_trace.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _ip]
         L.orc_render.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                  C.c_uint32, C.c_int, C.c_int, _dp, _dp, C.POINTER(C.c_uint64)]
         L.orc_format_ppm.restype = C.c_long
@@ -164,6 +165,17 @@ class Oracle:
         out = np.zeros_like(d)
         self.lib.orc_sky(d.shape[0], dp, out.ctypes.data_as(_dp))
         return out
+
+    def trace(self, scene, o, d, max_depth, u):
+        """calcColour for given rays, the uniforms of every scatter injected: u is [n][max_depth][3]."""
+        o, op = _d(o)
+        d, dp = _d(d)
+        n = o.shape[0]
+        u, up = _d(np.asarray(u, dtype=np.float64).reshape(n, max(max_depth, 0), 3))
+        rgb = np.zeros((n, 3))
+        rays = np.zeros(n, dtype=np.int32)
+        self.lib.orc_trace(scene, n, op, dp, max_depth, up, rgb.ctypes.data_as(_dp), rays.ctypes.data_as(_ip))
+        return dict(rgb=rgb, rays=rays)
 
     # -- render ------------------------------------------------------------------------------
     def render(self, scene, cam, W, H, spp_begin, spp_end, max_depth=50, mode=0, seed_a=1, seed_b=2, threads=1,

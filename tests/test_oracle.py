@@ -239,3 +239,45 @@ def test_round2_config_quirk_kats(kat):
     txt = REFERENCE_CONFIG.replace("(0,1,0)\t", "(%d,%d,%d)\t" % tuple(m["up_in_file"])).replace(m["missing"], m["missing"] + "X").replace("= 400", "= 999")
     s, used_defaults = host.read_settings(txt)
     assert used_defaults and list(s["cameraUpOrient"]) == m["up_after"] and s["imageWidth"] == m["width_after"]
+
+
+# ---- round 3: whole calcColour paths derived by hand (kat.json: whole_paths); the same on the device in test_gpu_parity.py ----
+def test_round3_whole_path_kats_on_the_oracle(orc, kat):
+    import kat_cases
+    assert len(kat["whole_paths"]) >= 10
+
+    def trace_one(scene, o, d, max_depth, u):
+        hs = orc.scene_create(scene)
+        try:
+            return orc.trace(hs, o, d, max_depth, u)
+        finally:
+            orc.scene_free(hs)
+
+    assert kat_cases.run_path_cases(trace_one, kat, atol=1e-12) < 1e-12
+
+
+def test_orc_trace_is_the_render_loop_under_philox_numbers(orc):
+    """orc_trace with the uniforms philox mode would draw reproduces the oracle's own render of one pixel sample: the
+    injected-uniform path and the render share radiance(), this checks the indexing of `u` (the scatter at the k-th hit
+    takes block (pixel, sample, k + 1), words 0..2)."""
+    sc = orc.generate_scene(40, 1, 2)
+    hs = orc.scene_create(sc)
+    cam = orc.camera_setup()
+    W, H, depth, key = 16, 9, 12, (7, 9)
+    full, _, rays_full = orc.render(hs, cam, W, H, 0, 1, depth, mode=1, seed_a=key[0], seed_b=key[1], threads=1)
+    o, d, u = [], [], np.zeros((W * H, depth, 3))
+    for j in range(H):
+        for i in range(W):
+            pixel = j * W + i
+            b0 = orc.philox([pixel, 0, 0, 0], key)
+            f = lambda w: float(int(w) >> 8) / 16777216.0
+            rr, ang = np.sqrt(f(b0[2])), 2 * np.pi * f(b0[3])
+            oo, dd = orc.gen_ray(cam, W, H, [i], [j], [f(b0[0])], [f(b0[1])], [rr * np.cos(ang)], [rr * np.sin(ang)])
+            o.append(oo[0]); d.append(dd[0])
+            for k in range(depth):
+                b = orc.philox([pixel, 0, k + 1, 0], key)
+                u[len(o) - 1, k] = [f(b[0]), f(b[1]), f(b[2])]
+    got = orc.trace(hs, np.array(o), np.array(d), depth, u)
+    orc.scene_free(hs)
+    img = got["rgb"].reshape(H, W, 3)[::-1]                             # rows: the render stores the top row first
+    assert np.abs(img - full).max() < 1e-12 and int(got["rays"].sum()) == rays_full

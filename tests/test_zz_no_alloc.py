@@ -67,3 +67,46 @@ def test_noalloc_entry_point_matches_pt_render_twice_in_a_row():
         assert rays == rays_ref and np.array_equal(out, ref)
     finally:
         dev.close()
+
+
+def test_noalloc_entry_point_allocates_nothing_and_can_be_captured():
+    """The property the entry point exists for. (1) The device's free memory, as the driver reports it, does not move
+    across calls (a hipMalloc of any size would show: the driver hands out whole pages). (2) The call can be recorded
+    into a HIP graph (stream capture forbids allocation and synchronisation) and the graph replayed: each replay adds
+    the same samples again, so two replays into a cleared buffer give exactly twice pt_render's sums."""
+    import torch
+    from path_tracer_amd import Device, host
+    dev = Device(0)
+    try:
+        dev.set_scene(host.generate_scene(250, 1, 2))
+        dev.set_camera(host.camera_setup())
+        W, H, spp, seed = 160, 90, 4, 21
+        out = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        rays_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ref = torch.zeros_like(out)
+        rays_ref = dev.render(W, H, 0, spp, 50, seed, accum_ptr=ref.data_ptr(), want_rays=True)
+        dev.render_noalloc(W, H, 0, spp, 50, seed, out.data_ptr(), rays_dev.data_ptr())          # warm: code objects loaded
+        dev.synchronize(); torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        for k in range(3):
+            dev.render_noalloc(W, H, k, k + spp, 50, seed, out.data_ptr(), rays_dev.data_ptr())
+        dev.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, (free0, free1)
+
+        side = torch.cuda.Stream()
+        dev.set_stream(side.cuda_stream)                     # before the capture begins: pt_set_stream synchronises
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            dev.render_noalloc(W, H, 0, spp, 50, seed, out.data_ptr(), rays_dev.data_ptr())
+        torch.cuda.synchronize()
+        out.zero_(); rays_dev.zero_()
+        torch.cuda.synchronize()
+        graph.replay(); graph.replay()
+        torch.cuda.synchronize()
+        assert int(rays_dev.item()) == rays_ref                                    # each replay counts its own rays
+        assert ref.any() and torch.equal(out, 2 * ref)
+        del graph
+        dev.set_stream(None)
+    finally:
+        dev.close()
