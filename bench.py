@@ -298,6 +298,36 @@ def extras(dev, host, accum, W, H, spp, depth, scene, cam):
         return float(np.min(dev.kernel_times()))
 
     res = {"note": "kernel times (HIP events), best of the runs; not part of `value` or `roofline`"}
+
+    def frac(rays, n_sph, ms):
+        return rays * (FLOP_PER_TEST * n_sph + FLOP_PER_RAY_FIXED) / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS
+
+    def scan_line(reps, s, w=W, h=H, buf=accum, n_sph=None, d=depth):
+        """Full-scan workload: kernel ms (k_render<0> + k_tail) with the k_tail part apart, rays per launch, roofline fraction."""
+        dev.kernel_times()
+        r0 = dev.ray_count()
+        for _ in range(reps):
+            buf.zero_()
+            dev.render(w, h, 0, s, d, 42, accum_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        whole, tail = dev.kernel_times_split()
+        rays = (dev.ray_count() - r0) / reps
+        ms = float(np.min(whole))
+        return {"kernel_ms": ms, "k_tail_ms": float(np.min(tail)), "k_render_ms": ms - float(tail[int(np.argmin(whole))]),
+                "Msamples_per_s": w * h * s / ms / 1e3, "rays_per_sample": rays / (w * h * s),
+                "roofline_frac": frac(rays, n_sph if n_sph else len(scene["kind"]), ms)}
+
+    # the headline workload once more, with the split between the sample-loop kernel and the end-of-frame kernel
+    res["configs1_kernel_split"] = scan_line(3, spp)
+    # the north-star frame: the same scene at 1,024 spp (DEFAULT workload only: other sizes say so in their own line)
+    res["north_star_1080p_1024spp"] = scan_line(1, 1024)
+    # configs[3]: 10 % diffuse / 40 % metal / 50 % glass, maxDepth 100 (stress for divergence and path regeneration)
+    glassy = host.generate_scene(500, 1, 2, diffuse_below=0.1, metal_below=0.5)
+    dev.set_scene(glassy)
+    line = scan_line(3, spp, n_sph=len(glassy["kind"]), d=100)
+    line["spheres"] = len(glassy["kind"])
+    res["configs3_glass_metal_heavy_depth100"] = line
+    dev.set_scene(scene)
     dev.set_accel(1)
     kernel_ms(1, spp)
     ms = kernel_ms(3, spp)
@@ -321,13 +351,10 @@ def extras(dev, host, accum, W, H, spp, depth, scene, cam):
     dev.set_camera(host.camera_setup(aspect=400 / 225))
     sbuf = torch.zeros((225, 400, 3), dtype=torch.float32, device="cuda")
     kernel_ms(20, 100, 400, 225, sbuf)          # a 1.5 ms kernel: the clocks need some tens of launches to settle
-    r0 = dev.ray_count()
-    ms_small = kernel_ms(20, 100, 400, 225, sbuf)
-    rays_small = (dev.ray_count() - r0) / 20
     n_small = len(small["kind"])
-    res["configs0_scene_on_gpu_400x225_100spp"] = {
-        "spheres": n_small, "kernel_ms": ms_small, "Msamples_per_s": 400 * 225 * 100 / ms_small / 1e3,
-        "roofline_frac": rays_small * (FLOP_PER_TEST * n_small + FLOP_PER_RAY_FIXED) / (ms_small * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+    line = scan_line(20, 100, 400, 225, sbuf, n_sph=n_small, d=50)
+    line["spheres"] = n_small
+    res["configs0_scene_on_gpu_400x225_100spp"] = line
     dev.set_scene(scene)
     dev.set_camera(cam)
     return res
