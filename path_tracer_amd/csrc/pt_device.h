@@ -258,9 +258,50 @@ PT_DEV void scan_spheres(const SceneDev& sc, f3 o, f3 dh, float tmin, int prev, 
 // scan_quad and tier2 operation for operation, and the rule "smallest t, then largest index" does not depend on the
 // order of the comparisons, so the answer is bit for bit the one scan_spheres gives. Used by k_tail for the long
 // paths left at the end of a frame, where latency counts and most of the chip is idle.
-// `scan` = the scan records (SceneDev::scan) in global memory or a copy of them in LDS, n_pad as in SceneDev.
-template <int G, class RecPtr>
-PT_DEV void coop_scan(RecPtr scan, int n_pad, int sub, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
+//
+// Two phases per chunk of up to 32 quads per lane (round 3; the first version took the roots of every sphere): phase 1 is
+// tier 1 only, seven packed FMAs per pair and one compare per quad, and notes the quads this lane's line meets in a bit
+// mask; phase 2 revisits the noted quads (a line meets a handful of the spheres of a scene: most lanes note none, the
+// loop runs once or twice per chunk for the wave) and takes the roots there. Two fifths of the instructions per bounce.
+//
+// The records come through an accessor: quad(q, R) fills R[16] with quad q's record (SceneDev::scan layout).
+struct QuadsGlobal {                 // the scan records where pt_set_scene put them (global memory / L2)
+    const float* base;
+    PT_DEV void quad(int q, float (&R)[16]) const {
+        const float4* rec = reinterpret_cast<const float4*>(base + 16 * size_t(q));
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+        R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+    }
+};
+struct QuadsLds {                    // k_tail's copy in LDS, TRANSPOSED: 16-byte word c (0..3) of quad q sits at [c * nq + q],
+    const float4* base;              // so the G lanes of a group, which read consecutive quads, read consecutive 16-byte
+    int nq;                          // words (no bank conflicts; with the record layout of global memory they were 64 bytes apart: 4-way)
+    PT_DEV void quad(int q, float (&R)[16]) const {
+        const float4 r0 = base[q], r1 = base[nq + q], r2 = base[2 * nq + q], r3 = base[3 * nq + q];
+        R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+        R[8] = r2.x; R[9] = r2.y; R[10] = r2.z; R[11] = r2.w; R[12] = r3.x; R[13] = r3.y; R[14] = r3.z; R[15] = r3.w;
+    }
+};
+// tier 1 of one quad as scan_quad computes it: b and U of its four spheres
+PT_DEV void coop_tier1(const float (&R)[16], f3 dh, float ne, f3 p2, v2f (&B)[2], v2f (&U)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const v2f cx = v2f{R[8 * h + 0], R[8 * h + 1]}, cy = v2f{R[8 * h + 2], R[8 * h + 3]};
+        const v2f cz = v2f{R[8 * h + 4], R[8 * h + 5]}, nK = v2f{R[8 * h + 6], R[8 * h + 7]};
+        v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{ne, ne});
+        b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
+        b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
+        v2f u = __builtin_elementwise_fma(b, b, nK);
+        u = __builtin_elementwise_fma(cx, v2f{p2.x, p2.x}, u);
+        u = __builtin_elementwise_fma(cy, v2f{p2.y, p2.y}, u);
+        u = __builtin_elementwise_fma(cz, v2f{p2.z, p2.z}, u);
+        B[h] = b;
+        U[h] = u;
+    }
+}
+template <int G, class Quads>
+PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float tmin, int prev, float self_t, float& best_t, int& best_i) {
     const float od = dot(o, dh);
     const f3 p = fma3(dh, -od, o);
     const float ne = -dot(p, dh);
@@ -273,31 +314,42 @@ PT_DEV void coop_scan(RecPtr scan, int n_pad, int sub, f3 o, f3 dh, float tmin, 
     float best_d = __builtin_inff();
     best_i = -1;
     const int n_quads = n_pad >> 2;
-    for (int q = sub; q < n_quads; q += G) {
-        const auto* rec = reinterpret_cast<const float4*>(scan + 16 * size_t(q));
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-        const float R[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    constexpr int CHUNK = 32;                                            // quads per lane and chunk: one bit each
+    for (int q0 = sub; q0 < n_quads; q0 += G * CHUNK) {                  // (the lanes of a wave differ in `sub` only: same trip count +- 1)
+        // phase 1: which of my quads does the line meet?
+        uint32_t noted = 0u;
+        for (int i = 0; i < CHUNK && q0 + G * i < n_quads; ++i) {
+            float R[16];
+            recs.quad(q0 + G * i, R);
+            v2f B[2], U[2];
+            coop_tier1(R, dh, ne, p2, B, U);
+            const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
+            noted |= (m >= pp ? 1u : 0u) << i;
+        }
+        // phase 2: the roots, for the noted quads only
+        while (__any(noted != 0u)) {
+            if (noted != 0u) {
+                const int i = __builtin_ctz(noted);
+                noted &= noted - 1u;
+                const int q = q0 + G * i;
+                float R[16];
+                recs.quad(q, R);
+                v2f B[2], U[2];
+                coop_tier1(R, dh, ne, p2, B, U);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const v2f cx = v2f{R[8 * h + 0], R[8 * h + 1]}, cy = v2f{R[8 * h + 2], R[8 * h + 3]};
-            const v2f cz = v2f{R[8 * h + 4], R[8 * h + 5]}, nK = v2f{R[8 * h + 6], R[8 * h + 7]};
-            v2f b = __builtin_elementwise_fma(cx, v2f{dh.x, dh.x}, v2f{ne, ne});
-            b = __builtin_elementwise_fma(cy, v2f{dh.y, dh.y}, b);
-            b = __builtin_elementwise_fma(cz, v2f{dh.z, dh.z}, b);
-            v2f u = __builtin_elementwise_fma(b, b, nK);
-            u = __builtin_elementwise_fma(cx, v2f{p2.x, p2.x}, u);
-            u = __builtin_elementwise_fma(cy, v2f{p2.y, p2.y}, u);
-            u = __builtin_elementwise_fma(cz, v2f{p2.z, p2.z}, u);
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int j = 4 * q + 2 * h + k;
-                const float s = fast_sqrt(u[k] - pp);              // NaN for a line that misses: its bits are above +inf's
-                const float bp = b[k] - tmin;                      // the arithmetic of tier2, operation for operation
-                const float t1 = bp - s, t2 = bp + s;
-                const uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
-                const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));   // j rises within a lane: <= keeps the later index
-                best_d = ok ? __uint_as_float(tu) : best_d;
-                best_i = ok ? j : best_i;
+                    for (int k = 0; k < 2; ++k) {
+                        const int j = 4 * q + 2 * h + k;
+                        const float s = fast_sqrt(U[h][k] - pp);           // NaN for a line that misses: its bits are above +inf's
+                        const float bp = B[h][k] - tmin;                   // the arithmetic of tier2, operation for operation
+                        const float t1 = bp - s, t2 = bp + s;
+                        const uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
+                        const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));   // j rises within a lane: <= keeps the later index
+                        best_d = ok ? __uint_as_float(tu) : best_d;
+                        best_i = ok ? j : best_i;
+                    }
+                }
             }
         }
     }

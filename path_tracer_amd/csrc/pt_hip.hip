@@ -172,10 +172,14 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     __shared__ unsigned int my_counter;             // the job counter this wave asks first (it moves on when that one has run out)
     if (lane == 0) { wave_number = blockIdx.x; my_counter = blockIdx.x % PT_JOB_COUNTERS; }
 
-    // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining
+    // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining. Tile, first sample and row
+    // count of the two jobs live in LDS (job_lds: c_tx, c_ty, c_s0, c_vh, o_tx, o_ty), not in registers: the scan leaves
+    // no scalar register for them, and as loop-carried vector registers they cost copies in every iteration although
+    // only the regeneration below reads them (one broadcast ds_read_b128) and only a job switch writes them.
+    __shared__ __align__(16) int job_lds[8];
+    if (lane < 8) job_lds[lane] = lane == 3 ? 8 : 0;
     int parity = 0;
-    int c_tx = 0, c_ty = 0, c_s0 = 0, c_vh = 8, c_total = 0, c_next = 0;
-    int o_tx = 0, o_ty = 0;
+    int c_total = 0, c_next = 0;
     bool c_valid = false, o_valid = false, no_more_jobs = false;
 
     bool active = false;
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 // Waiting for them would idle every finished lane; instead its sums go to the frame now and the
                 // stragglers add their result straight to the frame when they end (integer sums: any order).
                 if (active && (sb >> 6) != parity) sb = 128;
-                if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
+                if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[4], job_lds[5], lane);
                 // A wave's first job is its own number (the launch has at most as many waves as jobs); the counter hands
                 // out the rest. Thousands of waves asking one address at the same moment would queue for ~0.1 ms.
                 int job = int(blockIdx.x);
@@ -320,44 +324,50 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need_mask), 0));
             const bool from_new = rank >= rem;
             const int k = from_new ? rank - rem : c_next + rank;                     // item number within its job
-            if (!active && (!from_new || (have_new && k < n_total))) {               // (a bottom-edge tile's job may hold fewer than 64 items)
-                const int tx = from_new ? n_tx : c_tx, ty = from_new ? n_ty : c_ty, s0 = from_new ? n_s0 : c_s0;
-                // item k = (sample, row, column) with the column fastest, over the rows of the tile that exist
-                int row = (k >> 3) & 7, smp = k >> 6;
-                if (c_vh != 8 || n_vh != 8) {                                        // wave-uniform: a tile of the bottom edge
-                    const int vh = from_new ? n_vh : c_vh;
-                    const int t = k >> 3;
-                    static_assert(8 * PT_MAX_SPP_CHUNK <= (1 << 20), "t = k >> 3 < vh * spp_chunk must stay below 2^20 for the reciprocal quotient");
-                    smp = int((float(t) + 0.5f) * __builtin_amdgcn_rcpf(float(vh)));  // t / vh for vh <= 8, t < 2^20: the quotient is at least 1/16 from an integer
-                    row = t - smp * vh;
-                }
-                const int x = tx * 8 + (k & 7), py = ty * 8 + row;                   // py from the top
-                if (x < P.W) {                                                       // (max_depth >= 1: the host launches nothing for 0)
-                    sb = row * 8 + (k & 7) + 64 * (from_new ? (parity ^ 1) : parity);
-                    px = x;
-                    j = P.H - 1 - py;                                                // Path Tracer.cpp:298
-                    pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
-                    sample = uint32_t(s0 + smp);
-                    bounce = 0;
-                    prev = -1;
-                    top_pixel = uint32_t(py) * uint32_t(P.W) + uint32_t(px);
-                    fresh = active = true;
-                }
+            // Straight-line at lane level too (selects, then ONE guarded block of assignments): nested conditions cost a
+            // chain of register copies at every level for the ten values a new path sets.
+            const int4 cj = *reinterpret_cast<const int4*>(job_lds);                 // c_tx, c_ty, c_s0, c_vh (broadcast read)
+            const int tx = from_new ? n_tx : cj.x, ty = from_new ? n_ty : cj.y, s0 = from_new ? n_s0 : cj.z;
+            // item k = (sample, row, column) with the column fastest, over the rows of the tile that exist
+            int row = (k >> 3) & 7, smp = k >> 6;
+            if (__builtin_amdgcn_readfirstlane(cj.w) != 8 || n_vh != 8) {            // wave-uniform: a tile of the bottom edge
+                const int vh = from_new ? n_vh : cj.w;
+                const int t = k >> 3;
+                static_assert(8 * PT_MAX_SPP_CHUNK <= (1 << 20), "t = k >> 3 < vh * spp_chunk must stay below 2^20 for the reciprocal quotient");
+                smp = int((float(t) + 0.5f) * __builtin_amdgcn_rcpf(float(vh)));      // t / vh for vh <= 8, t < 2^20: the quotient is at least 1/16 from an integer
+                row = t - smp * vh;
+            }
+            const int x = tx * 8 + (k & 7), py = ty * 8 + row;                       // py from the top
+            // (a bottom-edge tile's job may hold fewer than 64 items; max_depth >= 1: the host launches nothing for 0)
+            if (!active & (!from_new | (have_new & (k < n_total))) & (x < P.W)) {
+                sb = row * 8 + (k & 7) + 64 * (from_new ? (parity ^ 1) : parity);
+                px = x;
+                j = P.H - 1 - py;                                                    // Path Tracer.cpp:298
+                pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
+                sample = uint32_t(s0 + smp);
+                bounce = 0;
+                prev = -1;
+                top_pixel = uint32_t(py) * uint32_t(P.W) + uint32_t(px);
+                fresh = active = true;
             }
             if (have_new) {
-                o_tx = c_tx; o_ty = c_ty; o_valid = c_valid;
+                if (lane < 4) job_lds[4 + lane] = lane == 0 ? cj.x : cj.y;           // o_tx, o_ty (lanes 2, 3 write spare words)
+                o_valid = c_valid;
                 parity ^= 1;
-                c_tx = n_tx; c_ty = n_ty; c_s0 = n_s0; c_vh = n_vh; c_total = n_total;
+                if (lane < 4) job_lds[lane] = lane == 0 ? n_tx : lane == 1 ? n_ty : lane == 2 ? n_s0 : n_vh;
+                c_total = n_total;
                 c_next = min(n_need - max(rem, 0), n_total);
                 c_valid = true;
             } else {
                 c_next += min(n_need, max(rem, 0));
             }
         }
-        if (!__any(active)) {
-            if constexpr (MODE != 0) { if (no_more_jobs) break; }
-            continue;                                        // MODE 0: the check at the top of the loop ends the wave
-        }
+        if constexpr (MODE != 0) {
+            if (!__any(active)) {
+                if (no_more_jobs) break;
+                continue;
+            }
+        }                                                    // MODE 0: the block below is skipped, the check at the top of the loop ends the wave
         { const int live = __popcll(__ballot(MODE == 0 ? active : (active && !walking))); (void)live;
           PT_STAT_ADD(0, 1);                                 // wave-level ray segments
           PT_STAT_ADD(1, live); }                            // live lanes in them
@@ -384,14 +394,20 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 const CameraDev cam = load_camera(cam_ptr);
                 gen_ray(cam, px, j, P.inv_w1, P.inv_h1, u24(r.x), u24(r.y), rad * cos_rev(ang), rad * sin_rev(ang), o, d);
                 thr = mk3(1, 1, 1);
-                dh = normalise(d, len);
+                if constexpr (MODE != 0) dh = normalise(d, len);
             }
+            bool ok = true;
             if (hit) {
                 f3 atten;
-                const bool ok = shade(mat, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
+                ok = shade(mat, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
                 thr = thr * atten;                                                   // Path Tracer.cpp:97
                 o = h.p;
-                dh = normalise(d, len);
+                if constexpr (MODE != 0) dh = normalise(d, len);
+            }
+            // MODE 0: one normalise for both kinds of new ray (eight vector instructions fewer per iteration; the grid
+            // kernels have no register to spare for the longer life of `d` and keep one in each branch)
+            if constexpr (MODE == 0) { if (fresh | hit) dh = normalise(d, len); }
+            if (hit) {
                 self_t = self_far_root(h.r, h.n, h.front, dh);
                 active = ok;                                                         // Path Tracer.cpp:100 -> black
             }
@@ -424,8 +440,8 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     }
 
     // ---- the last sums to the frame ----
-    if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), o_tx, o_ty, lane);
-    if (c_valid) flush_bank(P, acc + 192 * parity, c_tx, c_ty, lane);
+    if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[4], job_lds[5], lane);
+    if (c_valid) flush_bank(P, acc + 192 * parity, job_lds[0], job_lds[1], lane);
     unsigned int r = rays;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
@@ -468,18 +484,22 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     extern __shared__ __align__(16) unsigned char tail_lds[];
     const int tid = threadIdx.x, sub = tid & (G - 1);
     const int n_rec_floats = (P.scene.n_pad + 8) * 4;
-    float* l_scan = reinterpret_cast<float*>(tail_lds);
+    const int nq_alloc = n_rec_floats / 16;                                // quads of the copy (the scene's and the two of the padding)
+    float4* l_scan = reinterpret_cast<float4*>(tail_lds);
     GeomRec* l_geom = reinterpret_cast<GeomRec*>(tail_lds + size_t(n_rec_floats) * 4);
     MatRec* l_mat = reinterpret_cast<MatRec*>(reinterpret_cast<unsigned char*>(l_geom) + size_t(P.scene.n) * sizeof(GeomRec));
     if constexpr (LDS) {
+        // the scan records transposed (QuadsLds): 16-byte word c of quad q to [c * nq_alloc + q]
         const float4* gs = reinterpret_cast<const float4*>(P.scene.scan);
-        for (int i = tid; i < n_rec_floats / 4; i += 256) reinterpret_cast<float4*>(l_scan)[i] = gs[i];
+        for (int i = tid; i < n_rec_floats / 4; i += 256) l_scan[(i & 3) * nq_alloc + (i >> 2)] = gs[i];
         const double2* gg = reinterpret_cast<const double2*>(P.scene.geom);
         for (int i = tid; i < P.scene.n * 3; i += 256) reinterpret_cast<double2*>(l_geom)[i] = gg[i];
         const float4* gm = reinterpret_cast<const float4*>(P.scene.mat);
         for (int i = tid; i < P.scene.n * 2; i += 256) reinterpret_cast<float4*>(l_mat)[i] = gm[i];
         __syncthreads();
     }
+    const QuadsLds quads_lds{l_scan, nq_alloc};
+    const QuadsGlobal quads_global{P.scene.scan};
 #ifdef PT_WAVEPROF
     tp_staged = wall_clock64();
 #endif
@@ -496,6 +516,8 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     float len = 1.0f, self_t = 0.0f;
     int prev = -1, bounce = 0;
     uint32_t pixel = 0, sample = 0, top_pixel = 0;
+    u4 pc; pc.x = pc.y = pc.z = pc.w = 0u;                                // philox block of bounce pc_first + sub of the group's path
+    int pc_first = -(1 << 30);
     for (;;) {
         // a group without a path takes the next occupied slot of its sequence (the lanes of a group read the same words)
         while (!active && more) {
@@ -508,6 +530,7 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
             o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
             len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
             pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
+            pc_first = -(1 << 30);                                        // the philox blocks held are another path's
             active = true;
         }
         if (!__any(active)) break;                                        // (waves of a workgroup leave independently: no barrier below)
@@ -517,8 +540,8 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
         if (active) {
             if (sub == 0) ++rays;
             float bt; int bi;
-            if constexpr (LDS) coop_scan<G>(l_scan, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            else coop_scan<G>(P.scene.scan, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if constexpr (LDS) coop_scan<G>(quads_lds, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            else coop_scan<G>(quads_global, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 if (sub == 0) {
@@ -539,9 +562,19 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
                 if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
                     active = false;
                 } else {
-                    const u4 r = philox4x32_10(pixel, sample, uint32_t(bounce), 0u, P.key0, P.key1);
+                    // The philox block of this scatter. A block depends on (pixel, sample, bounce) only, so the G lanes of a
+                    // group, instead of all computing the same one, compute those of the next G bounces at once (lane `sub`:
+                    // bounce pc_first + sub) and every scatter fetches its own from the lane that holds it: the block's ten
+                    // dependent rounds leave the per-bounce chain of a long path except once in G bounces. When one group of
+                    // the wave needs new blocks all groups in this branch take theirs (same instructions either way).
+                    if (__any(bounce < pc_first || bounce >= pc_first + G)) {
+                        pc_first = bounce;
+                        pc = philox4x32_10(pixel, sample, uint32_t(bounce + sub), 0u, P.key0, P.key1);
+                    }
+                    const int holder = (tid & 63 & ~(G - 1)) + (bounce - pc_first);
+                    const uint32_t rx = __shfl(pc.x, holder), ry = __shfl(pc.y, holder), rz = __shfl(pc.z, holder);
                     f3 d, atten;
-                    const bool ok = shade(mat, dh, len, h.n, h.front, u24(r.x), u24(r.y), u24(r.z), d, atten);
+                    const bool ok = shade(mat, dh, len, h.n, h.front, u24(rx), u24(ry), u24(rz), d, atten);
                     thr = thr * atten;                                               // Path Tracer.cpp:97
                     o = h.p;
                     dh = normalise(d, len);
