@@ -203,11 +203,6 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     // record; lanes whose path ended take a new (sample, pixel) item; ONE philox block per lane then
     // feeds either the camera ray of a new path (bounce 0) or the scatter of a continuing one.
     for (;;) {
-        if constexpr (MODE == 0) {
-            // End of the frame: no job is left and this wave holds only a few paths (the long ones). They are finished
-            // below, one at a time, with the spheres spread over the lanes.
-            if (no_more_jobs && __popcll(__ballot(active)) <= PT_TAIL_PATHS) break;
-        }
         HitRec h;
         MatRec mat;
         bool hit = false;
@@ -418,6 +413,12 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                     pending = !gw.live;                                              // the big list alone answers this ray
                 }
             }
+        }
+        if constexpr (MODE == 0) {
+            // End of the frame: no job is left and this wave holds only a few paths (the long ones). They go to k_tail,
+            // which finishes them with the spheres spread over the lanes. (Tested at the bottom of the loop: at the top
+            // hipcc kept two copies of the path state and copied one to the other and back in every iteration.)
+            if (no_more_jobs && __popcll(__ballot(active)) <= PT_TAIL_PATHS) break;
         }
     }
 
