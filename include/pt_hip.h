@@ -68,7 +68,10 @@ int pt_synchronize(pt_handle h);
 /* Replaces HittableList::add of Sphere objects with their materials (HittableList.cpp:5-7,
  * Sphere.h:25, Lambertian.h:20, Metal.h:21, Dielectric.h:23), flattened by the host in list order.
  * kind[i] is PT_LAMBERTIAN / PT_METAL / PT_DIELECTRIC; albedo is used by the first two, fuzz by
- * Metal (already clamped to <= 1, Metal.h:21), ior by Dielectric. Arrays are read during the call. */
+ * Metal (already clamped to <= 1, Metal.h:21), ior by Dielectric. Arrays are read during the call.
+ * Rejected with PT_ERR_INVALID: a non-finite centre, a radius <= 0, an unknown kind, a Dielectric with ior <= 0, an
+ * albedo component that is negative or not finite (the order-independent fixed-point sums of pt_render hold
+ * non-negative radiance only). */
 int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const double* cz, const double* r,
                  const int* kind, const double* albedo_r, const double* albedo_g, const double* albedo_b,
                  const double* fuzz, const double* ior);

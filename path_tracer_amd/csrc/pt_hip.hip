@@ -89,10 +89,11 @@ PT_DEV CameraDev load_camera(const float* p) {
     return c;
 }
 
-// Radiance in [0, 1] per channel (every attenuation and the sky are <= 1) to unsigned Q32.32.
+// Radiance per channel to unsigned Q32.32. It is never negative and never a NaN: the sky is in [0.5, 1] and every
+// attenuation is a finite, non-negative albedo or 1 (pt_set_scene rejects anything else), so no clamp is needed here
+// (round 3: two instructions per channel and path fewer); the conversions saturate what exceeds 2^32.
 // Integer sums make the frame independent of the order in which lanes and jobs finish.
 PT_DEV unsigned long long to_fx(float v) {
-    v = __builtin_fmaxf(v, 0.0f);                                   // also drops a NaN (maxnum returns the number)
     const uint32_t hi = uint32_t(v);                                 // whole part: the conversion truncates and saturates
     const uint32_t lo = uint32_t(__builtin_amdgcn_fractf(v) * 4294967296.0f);   // fraction, exact (a power-of-two scale), truncated
     return ((unsigned long long)hi << 32) | lo;
@@ -173,11 +174,14 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     if (lane == 0) { wave_number = blockIdx.x; my_counter = blockIdx.x % PT_JOB_COUNTERS; }
 
     // wave-uniform job state: `c_` the job items are drawn from, `o_` the one still draining. Tile, first sample and row
-    // count of the two jobs live in LDS (job_lds: c_tx, c_ty, c_s0, c_vh, o_tx, o_ty), not in registers: the scan leaves
-    // no scalar register for them, and as loop-carried vector registers they cost copies in every iteration although
-    // only the regeneration below reads them (one broadcast ds_read_b128) and only a job switch writes them.
-    __shared__ __align__(16) int job_lds[8];
-    if (lane < 8) job_lds[lane] = lane == 3 ? 8 : 0;
+    // count of the two jobs live in LDS, not in registers: job_lds[parity] = the current job's (tx, ty, s0, vh),
+    // job_lds[parity ^ 1] the draining one's, like the two banks of sums. The scan leaves no scalar register for them, and
+    // as loop-carried vector registers they cost copies in every iteration although only the regeneration below reads
+    // them and only a job switch writes them. A new job is written to the slot of the job that has just been flushed;
+    // a lane then reads the record of the job its item comes from with ONE ds_read_b128 at a per-lane address.
+    __shared__ int4 job_lds[2];
+    if (lane < 2) job_lds[lane] = int4{0, 0, 0, 8};
+    bool c_edge = false;                            // the current job's tile is one of the bottom edge (fewer than 8 rows)
     int parity = 0;
     int c_total = 0, c_next = 0;
     bool c_valid = false, o_valid = false, no_more_jobs = false;
@@ -274,7 +278,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 // Waiting for them would idle every finished lane; instead its sums go to the frame now and the
                 // stragglers add their result straight to the frame when they end (integer sums: any order).
                 if (active && (sb >> 6) != parity) sb = 128;
-                if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[4], job_lds[5], lane);
+                if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[parity ^ 1].x, job_lds[parity ^ 1].y, lane);
                 // A wave's first job is its own number (the launch has at most as many waves as jobs); the counter hands
                 // out the rest. Thousands of waves asking one address at the same moment would queue for ~0.1 ms.
                 int job = int(blockIdx.x);
@@ -314,6 +318,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                     const int s_end = fine ? min(n_s0 + P.spp_fine, P.spp_end) : min(n_s0 + P.spp_chunk, P.fine_begin);
                     n_vh = min(8, P.H - 8 * n_ty);                                   // rows of the tile inside the image
                     n_total = 8 * n_vh * (s_end - n_s0);
+                    if (lane == 0) job_lds[parity ^ 1] = int4{n_tx, n_ty, n_s0, n_vh};   // (the draining job's sums have just gone to the frame)
                 }
             }
             const int rank = __builtin_amdgcn_mbcnt_hi(uint32_t(need_mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need_mask), 0));
@@ -321,12 +326,13 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             const int k = from_new ? rank - rem : c_next + rank;                     // item number within its job
             // Straight-line at lane level too (selects, then ONE guarded block of assignments): nested conditions cost a
             // chain of register copies at every level for the ten values a new path sets.
-            const int4 cj = *reinterpret_cast<const int4*>(job_lds);                 // c_tx, c_ty, c_s0, c_vh (broadcast read)
-            const int tx = from_new ? n_tx : cj.x, ty = from_new ? n_ty : cj.y, s0 = from_new ? n_s0 : cj.z;
+            const int slot = (from_new ? 1 : 0) ^ parity;                            // job slot and bank of sums of this lane's item
+            const int4 jb = job_lds[slot];                                           // tx, ty, s0, vh of that job
+            const int tx = jb.x, ty = jb.y, s0 = jb.z;
             // item k = (sample, row, column) with the column fastest, over the rows of the tile that exist
             int row = (k >> 3) & 7, smp = k >> 6;
-            if (__builtin_amdgcn_readfirstlane(cj.w) != 8 || n_vh != 8) {            // wave-uniform: a tile of the bottom edge
-                const int vh = from_new ? n_vh : cj.w;
+            if (c_edge || n_vh != 8) {                                               // wave-uniform: a tile of the bottom edge
+                const int vh = jb.w;
                 const int t = k >> 3;
                 static_assert(8 * PT_MAX_SPP_CHUNK <= (1 << 20), "t = k >> 3 < vh * spp_chunk must stay below 2^20 for the reciprocal quotient");
                 smp = int((float(t) + 0.5f) * __builtin_amdgcn_rcpf(float(vh)));      // t / vh for vh <= 8, t < 2^20: the quotient is at least 1/16 from an integer
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             const int x = tx * 8 + (k & 7), py = ty * 8 + row;                       // py from the top
             // (a bottom-edge tile's job may hold fewer than 64 items; max_depth >= 1: the host launches nothing for 0)
             if (!active & (!from_new | (have_new & (k < n_total))) & (x < P.W)) {
-                sb = row * 8 + (k & 7) + 64 * (from_new ? (parity ^ 1) : parity);
+                sb = row * 8 + (k & 7) + 64 * slot;
                 px = x;
                 j = P.H - 1 - py;                                                    // Path Tracer.cpp:298
                 pixel = uint32_t(j) * uint32_t(P.W) + uint32_t(px);
@@ -346,10 +352,9 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
                 fresh = active = true;
             }
             if (have_new) {
-                if (lane < 4) job_lds[4 + lane] = lane == 0 ? cj.x : cj.y;           // o_tx, o_ty (lanes 2, 3 write spare words)
                 o_valid = c_valid;
-                parity ^= 1;
-                if (lane < 4) job_lds[lane] = lane == 0 ? n_tx : lane == 1 ? n_ty : lane == 2 ? n_s0 : n_vh;
+                parity ^= 1;                                                         // the new job's slot and bank become the current ones
+                c_edge = n_vh != 8;
                 c_total = n_total;
                 c_next = min(n_need - max(rem, 0), n_total);
                 c_valid = true;
@@ -441,8 +446,8 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     }
 
     // ---- the last sums to the frame ----
-    if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[4], job_lds[5], lane);
-    if (c_valid) flush_bank(P, acc + 192 * parity, job_lds[0], job_lds[1], lane);
+    if (o_valid) flush_bank(P, acc + 192 * (parity ^ 1), job_lds[parity ^ 1].x, job_lds[parity ^ 1].y, lane);
+    if (c_valid) flush_bank(P, acc + 192 * parity, job_lds[parity].x, job_lds[parity].y, lane);
     unsigned int r = rays;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s);
@@ -697,6 +702,7 @@ __global__ void k_scatter(int n, const int* kind, const double* albedo, const do
     if (k >= n) return;
     MatRec m;
     m.ar = float(albedo[3 * k]); m.ag = float(albedo[3 * k + 1]); m.ab = float(albedo[3 * k + 2]);
+    if (kind[k] == 2) m.ar = m.ag = m.ab = 1.0f;                   // as pt_set_scene stores a Dielectric (Dielectric.cpp:7)
     m.fuzz = float(fuzz[k]);
     const double i = ior[k];
     m.ior = float(i);
@@ -1103,6 +1109,9 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
         if (!(r[i] > 0.0) || !std::isfinite(r[i]) || !std::isfinite(cx[i]) || !std::isfinite(cy[i]) || !std::isfinite(cz[i]))
             return fail(h, PT_ERR_INVALID, "pt_set_scene: sphere with non-finite centre or non-positive radius");
         if (kind[i] == PT_DIELECTRIC && !(ior[i] > 0.0)) return fail(h, PT_ERR_INVALID, "pt_set_scene: dielectric with non-positive refractive index");
+        if (kind[i] != PT_DIELECTRIC && !(ar[i] >= 0.0 && ag[i] >= 0.0 && ab[i] >= 0.0 && std::isfinite(ar[i]) && std::isfinite(ag[i]) && std::isfinite(ab[i])))
+            return fail(h, PT_ERR_INVALID, "pt_set_scene: albedo must be finite and non-negative");       // the fixed-point sums rely on it
+        if (kind[i] == PT_METAL && !std::isfinite(fuzz[i])) return fail(h, PT_ERR_INVALID, "pt_set_scene: non-finite fuzz");
     }
     PT_HIP(h, hipSetDevice(h->device));
     PT_HIP(h, hipStreamSynchronize(h->stream));
@@ -1116,6 +1125,7 @@ int pt_set_scene(pt_handle h, int n, const double* cx, const double* cy, const d
         geom[i] = GeomRec{cx[i], cy[i], cz[i], r[i], 1 / r[i], r[i] * r[i]};   // Sphere.cpp:9, :28
         MatRec m;
         m.ar = float(ar[i]); m.ag = float(ag[i]); m.ab = float(ab[i]);
+        if (kind[i] == PT_DIELECTRIC) m.ar = m.ag = m.ab = 1.0f;                // its attenuation (Dielectric.cpp:7), whatever albedo the caller passed
         m.fuzz = float(fuzz[i] < 1 ? fuzz[i] : 1);                              // Metal.h:21
         const double ii = kind[i] == PT_DIELECTRIC ? ior[i] : 1.0;
         m.ior = float(ii); m.inv_ior = float(1.0 / ii);
