@@ -129,6 +129,91 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
     bank[lane * 3 + 0] = zero; bank[lane * 3 + 1] = zero; bank[lane * 3 + 2] = zero;
 }
 
+// Finishes the paths in slots[0 .. n_slots) (bounce < 0: empty slot), a path per GROUP of G lanes: the lanes of a group hold
+// the same path and share out the spheres (coop_scan); same arithmetic per sphere, same hit rule, same philox blocks and
+// integer sums straight to the frame as the sample loop, so the frame is bit for bit what the loop alone would produce. The
+// groups of the calling waves take the slots one by one through *next (a counter in LDS, zero on entry): a path of fifty
+// bounces then holds up one group while the others work through the rest. Returns this lane's count of rays traced.
+// Used by k_tail (slots in global memory written by k_render, scene copies in LDS) and by the end of k_render itself.
+template <int G, class Quads>
+PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, int n_slots, int* next, const Quads& quads,
+                                 const GeomRec* geom, const MatRec* mats, int tid, unsigned long long* iterations = nullptr) {
+    const int sub = tid & (G - 1);
+    bool more = true;                                                     // this group has not yet seen the end of the run
+    unsigned int rays = 0;
+    bool active = false;
+    f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(0, 0, 0);
+    float len = 1.0f, self_t = 0.0f;
+    int prev = -1, bounce = 0;
+    uint32_t pixel = 0, sample = 0, top_pixel = 0;
+    u4 pc; pc.x = pc.y = pc.z = pc.w = 0u;                                // philox block of bounce pc_first + sub of the group's path
+    int pc_first = -(1 << 30);
+    for (;;) {
+        // a group without a path takes the next occupied slot (the lanes of a group read the same words)
+        while (!active && more) {
+            int take = 0;
+            if (sub == 0) take = atomicAdd(next, 1);
+            take = __shfl(take, tid & 63 & ~(G - 1));
+            if (take >= n_slots) { more = false; break; }
+            const TailPath tp = slots[take];
+            if (tp.bounce < 0) continue;
+            o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
+            len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
+            pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
+            pc_first = -(1 << 30);                                        // the philox blocks held are another path's
+            active = true;
+        }
+        if (!__any(active)) break;                                        // (waves leave independently: no barrier in here)
+        if (iterations) ++*iterations;                                    // (the per-wave timing build only)
+        if (active) {
+            if (sub == 0) ++rays;
+            float bt; int bi;
+            coop_scan<G>(quads, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
+                const f3 c = thr * sky(dh.y);
+                if (sub == 0) {
+                    const size_t plane = size_t(P.W) * size_t(P.H);
+                    unsigned long long* dst = P.accum_fx + top_pixel;
+                    const unsigned long long vx = to_fx(c.x), vy = to_fx(c.y), vz = to_fx(c.z);
+                    if (vx) atomicAdd(dst, vx);
+                    if (vy) atomicAdd(dst + plane, vy);
+                    if (vz) atomicAdd(dst + 2 * plane, vz);
+                }
+                active = false;
+            } else {
+                const GeomRec g = geom[bi];
+                const MatRec mat = mats[bi];
+                const HitRec h = finish_hit(g, bi == prev, o, dh, 0.001 * double(len));
+                prev = bi;
+                ++bounce;
+                if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
+                    active = false;
+                } else {
+                    // The philox block of this scatter. A block depends on (pixel, sample, bounce) only, so the G lanes of a
+                    // group, instead of all computing the same one, compute those of the next G bounces at once (lane `sub`:
+                    // bounce pc_first + sub) and every scatter fetches its own from the lane that holds it: the block's ten
+                    // dependent rounds leave the per-bounce chain of a long path except once in G bounces. When one group of
+                    // the wave needs new blocks all groups in this branch take theirs (same instructions either way).
+                    if (__any(bounce < pc_first || bounce >= pc_first + G)) {
+                        pc_first = bounce;
+                        pc = philox4x32_10(pixel, sample, uint32_t(bounce + sub), 0u, P.key0, P.key1);
+                    }
+                    const int holder = (tid & 63 & ~(G - 1)) + (bounce - pc_first);
+                    const uint32_t rx = __shfl(pc.x, holder), ry = __shfl(pc.y, holder), rz = __shfl(pc.z, holder);
+                    f3 d, atten;
+                    const bool ok = shade(mat, dh, len, h.n, h.front, u24(rx), u24(ry), u24(rz), d, atten);
+                    thr = thr * atten;                                               // Path Tracer.cpp:97
+                    o = h.p;
+                    dh = normalise(d, len);
+                    self_t = self_far_root(h.r, h.n, h.front, dh);
+                    active = ok;                                                     // Path Tracer.cpp:100 -> black
+                }
+            }
+        }
+    }
+    return rays;
+}
+
 // Persistent waves. Each wave pulls jobs (8x8 tile x sample chunk) from a global counter and hands
 // the job's (sample, pixel-slot) items to its lanes as their paths end. When a job's items run out
 // the wave moves straight on to the next job while the last paths of the previous one are still in
@@ -145,6 +230,9 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #endif
 #ifndef PT_TAIL_PATHS
 #define PT_TAIL_PATHS 16            // a wave left with at most this many paths and no job hands them to k_tail
+#endif
+#ifndef PT_TAIL_GROUP
+#define PT_TAIL_GROUP 16            // lanes that share one path at the end of a frame
 #endif
 #ifndef PT_GRID_RATIO
 #define PT_GRID_RATIO 3             // answers are handled once they outnumber the walks in progress by this factor
@@ -428,6 +516,8 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
     }
 
     // ---- the last few paths of this wave go to its slots for k_tail (tail of the frame); the other slots are marked empty ----
+    // (Finishing them here instead, with finish_paths on the wave's own sixteen, was measured in round 3: the same frame
+    // time. What the end of a small frame waits for is the longest path, about 3 us per bounce either way, not the kernel boundary.)
     if constexpr (MODE == 0) {
         const unsigned long long live = __ballot(active);
         const int n_live = __popcll(live);
@@ -469,9 +559,6 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 // sixteen groups take them one by one through a counter in LDS: a path of fifty bounces then holds up one group while
 // the others work through the rest of the run (with a fixed slot sequence per group the longest sequence, two or three
 // long paths in a row, set the length of the kernel). No global counter, so nothing for thousands of groups to queue at.
-#ifndef PT_TAIL_GROUP
-#define PT_TAIL_GROUP 16
-#endif
 #ifndef PT_TAIL_LDS_MAX
 #define PT_TAIL_LDS_MAX 65536        // a workgroup's LDS limit: the scene copies of k_tail<true> must fit
 #endif
@@ -485,10 +572,10 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
 #ifdef PT_WAVEPROF
     const unsigned long long tp_start = wall_clock64();
-    unsigned long long tp_iters = 0, tp_staged = 0;
+    unsigned long long tp_staged = 0;
 #endif
     extern __shared__ __align__(16) unsigned char tail_lds[];
-    const int tid = threadIdx.x, sub = tid & (G - 1);
+    const int tid = threadIdx.x;
     const int n_rec_floats = (P.scene.n_pad + 8) * 4;
     const int nq_alloc = n_rec_floats / 16;                                // quads of the copy (the scene's and the two of the padding)
     float4* l_scan = reinterpret_cast<float4*>(tail_lds);
@@ -514,82 +601,17 @@ __global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
     __syncthreads();
     const int per_block = (P.n_tail_slots + int(gridDim.x) - 1) / int(gridDim.x);
     const int run_begin = int(blockIdx.x) * per_block, run_end = min(run_begin + per_block, P.n_tail_slots);
-    bool more = true;                                                     // this group has not yet seen the end of the run
-    const TailPath* slots = tail_slots(P);
-    unsigned int rays = 0;
-    bool active = false;
-    f3 o = mk3(0, 0, 0), dh = mk3(0, 0, 1), thr = mk3(0, 0, 0);
-    float len = 1.0f, self_t = 0.0f;
-    int prev = -1, bounce = 0;
-    uint32_t pixel = 0, sample = 0, top_pixel = 0;
-    u4 pc; pc.x = pc.y = pc.z = pc.w = 0u;                                // philox block of bounce pc_first + sub of the group's path
-    int pc_first = -(1 << 30);
-    for (;;) {
-        // a group without a path takes the next occupied slot of its sequence (the lanes of a group read the same words)
-        while (!active && more) {
-            int take = 0;
-            if (sub == 0) take = atomicAdd(&run_next, 1);
-            take = __shfl(take, tid & 63 & ~(G - 1)) + run_begin;
-            if (take >= run_end) { more = false; break; }
-            const TailPath tp = slots[take];
-            if (tp.bounce < 0) continue;
-            o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
-            len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
-            pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
-            pc_first = -(1 << 30);                                        // the philox blocks held are another path's
-            active = true;
-        }
-        if (!__any(active)) break;                                        // (waves of a workgroup leave independently: no barrier below)
+    unsigned int rays;
 #ifdef PT_WAVEPROF
-        ++tp_iters;
+    unsigned long long tp_iters = 0;
 #endif
-        if (active) {
-            if (sub == 0) ++rays;
-            float bt; int bi;
-            if constexpr (LDS) coop_scan<G>(quads_lds, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            else coop_scan<G>(quads_global, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
-            if (bi < 0) {                                                            // Path Tracer.cpp:105-107
-                const f3 c = thr * sky(dh.y);
-                if (sub == 0) {
-                    const size_t plane = size_t(P.W) * size_t(P.H);
-                    unsigned long long* dst = P.accum_fx + top_pixel;
-                    const unsigned long long vx = to_fx(c.x), vy = to_fx(c.y), vz = to_fx(c.z);
-                    if (vx) atomicAdd(dst, vx);
-                    if (vy) atomicAdd(dst + plane, vy);
-                    if (vz) atomicAdd(dst + 2 * plane, vz);
-                }
-                active = false;
-            } else {
-                const GeomRec g = LDS ? l_geom[bi] : P.scene.geom[bi];
-                const MatRec mat = LDS ? l_mat[bi] : P.scene.mat[bi];
-                const HitRec h = finish_hit(g, bi == prev, o, dh, 0.001 * double(len));
-                prev = bi;
-                ++bounce;
-                if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
-                    active = false;
-                } else {
-                    // The philox block of this scatter. A block depends on (pixel, sample, bounce) only, so the G lanes of a
-                    // group, instead of all computing the same one, compute those of the next G bounces at once (lane `sub`:
-                    // bounce pc_first + sub) and every scatter fetches its own from the lane that holds it: the block's ten
-                    // dependent rounds leave the per-bounce chain of a long path except once in G bounces. When one group of
-                    // the wave needs new blocks all groups in this branch take theirs (same instructions either way).
-                    if (__any(bounce < pc_first || bounce >= pc_first + G)) {
-                        pc_first = bounce;
-                        pc = philox4x32_10(pixel, sample, uint32_t(bounce + sub), 0u, P.key0, P.key1);
-                    }
-                    const int holder = (tid & 63 & ~(G - 1)) + (bounce - pc_first);
-                    const uint32_t rx = __shfl(pc.x, holder), ry = __shfl(pc.y, holder), rz = __shfl(pc.z, holder);
-                    f3 d, atten;
-                    const bool ok = shade(mat, dh, len, h.n, h.front, u24(rx), u24(ry), u24(rz), d, atten);
-                    thr = thr * atten;                                               // Path Tracer.cpp:97
-                    o = h.p;
-                    dh = normalise(d, len);
-                    self_t = self_far_root(h.r, h.n, h.front, dh);
-                    active = ok;                                                     // Path Tracer.cpp:100 -> black
-                }
-            }
-        }
-    }
+#ifdef PT_WAVEPROF
+    unsigned long long* const it = &tp_iters;
+#else
+    unsigned long long* const it = nullptr;
+#endif
+    if constexpr (LDS) rays = finish_paths<G>(P, tail_slots(P) + run_begin, run_end - run_begin, &run_next, quads_lds, l_geom, l_mat, tid, it);
+    else rays = finish_paths<G>(P, tail_slots(P) + run_begin, run_end - run_begin, &run_next, quads_global, P.scene.geom, P.scene.mat, tid, it);
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) rays += __shfl_xor(rays, s);
 #ifdef PT_WAVEPROF
