@@ -353,13 +353,31 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
             }
         }
     }
+    // The group's closest hit, in every lane of the group. "Smaller t, then larger index" is a total order, so combining
+    // each lane with the lane 8, 4, 2 and 1 places around the group's ring leaves the group's best everywhere. A group of
+    // 16 lanes is a DPP row: the other lane's value comes through a row rotation inside the vector ALU (round 3; the
+    // cross-lane shuffles this replaces went through the LDS crossbar, two round trips of its latency per step, in the
+    // dependent chain of every bounce of the frame's longest path).
+    if constexpr (G == 16) {
+#define PT_ROR_STEP(CTRL)                                                                                                  \
+        {                                                                                                                  \
+            const float ot = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(best_d), CTRL, 0xf, 0xf, false)); \
+            const int oi = __builtin_amdgcn_update_dpp(0, best_i, CTRL, 0xf, 0xf, false);                                  \
+            const bool take = (ot < best_d) | ((ot == best_d) & (oi > best_i));                                            \
+            best_d = take ? ot : best_d;                                                                                   \
+            best_i = take ? oi : best_i;                                                                                   \
+        }
+        PT_ROR_STEP(0x128) PT_ROR_STEP(0x124) PT_ROR_STEP(0x122) PT_ROR_STEP(0x121)      // row_ror:8, 4, 2, 1
+#undef PT_ROR_STEP
+    } else {
 #pragma unroll
-    for (int s = G / 2; s > 0; s >>= 1) {
-        const float ot = __shfl_xor(best_d, s);
-        const int oi = __shfl_xor(best_i, s);
-        const bool take = (ot < best_d) | ((ot == best_d) & (oi > best_i));
-        best_d = take ? ot : best_d;
-        best_i = take ? oi : best_i;
+        for (int s = G / 2; s > 0; s >>= 1) {
+            const float ot = __shfl_xor(best_d, s);
+            const int oi = __shfl_xor(best_i, s);
+            const bool take = (ot < best_d) | ((ot == best_d) & (oi > best_i));
+            best_d = take ? ot : best_d;
+            best_i = take ? oi : best_i;
+        }
     }
     {
         const float sd = self_t - tmin;
