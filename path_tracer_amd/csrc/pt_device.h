@@ -31,7 +31,7 @@
 #define PT_DEV __device__ __forceinline__
 
 #ifdef PT_STATS
-extern __device__ unsigned long long g_stats[8];
+extern __device__ unsigned long long g_stats[16];
 #endif
 
 namespace ptd {
@@ -142,6 +142,9 @@ PT_DEV f3 sky(float dy) {
 // floats (and NaNs, for T < 0: Sphere.cpp:13) compare LARGER than every non-negative float when their bits are read as
 // unsigned integers, so that choice is one unsigned minimum, and "within [0, best_d]" one unsigned compare.
 PT_DEV void tier2(float T, float b, int j, int prev, float tmin, float& best_d, int& best_i) {
+#ifdef PT_STATS
+    if (threadIdx.x == 0) atomicAdd(&g_stats[8], 1ull);               // spheres whose roots were taken (wave level)
+#endif
     asm volatile("" : "+s"(j));   // keep j a scalar register: hipcc otherwise rewrites `j != prev` into a vector add per quad in tier 1
     const float s = fast_sqrt(T);
     const float bp = b - tmin;

@@ -101,7 +101,7 @@ PT_DEV unsigned long long to_fx(float v) {
 
 #ifdef PT_STATS
 // Diagnostic build only (tools/stats.sh): wave-level counts of where the instruction stream goes.
-__device__ unsigned long long g_stats[8];
+__device__ unsigned long long g_stats[16];
 #define PT_STAT_ADD(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define PT_STAT_ADD(i, v) do { } while (0)
@@ -316,11 +316,19 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
             }
         }
         const bool answered = MODE == 0 ? active : pending;      // lanes whose ray has (MODE 0: gets now) its closest hit
+#ifdef PT_STATS
+        if (__any(answered)) PT_STAT_ADD(9, 1);                  // iterations with a scan
+#endif
         if (answered) {
             ++rays;
             float bt; int bi;
             if constexpr (MODE == 0) scan_spheres(P.scene, o, dh, 0.001f * len, prev, self_t, bt, bi);
             else { grid_end(gw, 0.001f * len, prev, self_t, bt, bi); pending = false; }
+#ifdef PT_STATS
+            { const unsigned long long mm = __ballot(bi < 0), hm = __ballot(bi >= 0);
+              if (mm) PT_STAT_ADD(10, 1); if (hm) PT_STAT_ADD(11, 1);           // iterations that run the sky block / the finish block
+              PT_STAT_ADD(12, __popcll(mm)); PT_STAT_ADD(13, __popcll(hm)); }     // lanes in them
+#endif
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 if (sb < 128) {
@@ -1406,14 +1414,17 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
     if (int rc = render_core(h, width, height, spp_begin, spp_end, max_depth, seed, out, h->d_fx, h->d_counters, h->tail_cap, true)) return rc;
 #ifdef PT_STATS
     {
-        unsigned long long st[8];
+        unsigned long long st[16];
         PT_HIP(h, hipStreamSynchronize(h->stream));
         PT_HIP(h, hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stats), sizeof(st)));
+        if (st[9]) fprintf(stderr, "[pt stats] per scan iteration (%llu): quads %.2f, flagged quads %.2f, spheres resolved %.2f; sky block in %.3f of the iterations (%.1f lanes), finish block in %.3f (%.1f lanes)\n",
+                           st[9], double(st[2]) / st[9], double(st[3]) / st[9], double(st[8]) / st[9], double(st[10]) / st[9], st[10] ? double(st[12]) / st[10] : 0.0,
+                           double(st[11]) / st[9], st[11] ? double(st[13]) / st[11] : 0.0);
         fprintf(stderr, "[pt stats] wave_segments %llu live_lanes %llu (%.3f of 64) quads %llu tier2_quads %llu (%.4f) tier2_lanes %llu\n",
                 st[0], st[1], st[0] ? double(st[1]) / st[0] / 64 : 0.0, st[2], st[3], st[2] ? double(st[3]) / st[2] : 0.0, st[4]);
         if (st[5]) fprintf(stderr, "[pt stats] grid passes %llu (%.2f per wave segment) walking lanes %.3f of 64, lanes testing an entry %.3f of 64\n",
                            st[5], st[0] ? double(st[5]) / st[0] : 0.0, double(st[6]) / st[5], double(st[7]) / st[5]);
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z)));
     }
 #endif

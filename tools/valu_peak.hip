@@ -57,6 +57,8 @@ KERNEL_HEAD(k_max_vv)    asm volatile("v_max_f32 %0, %0, %1"     : "+v"(acc[i]) 
 KERNEL_HEAD(k_max3_vvv)  asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));  KERNEL_TAIL
 KERNEL_HEAD(k_cmp_vv)    asm volatile("v_cmp_ge_f32 vcc, %0, %1" : "+v"(acc[i]) : "v"(b) : "vcc");   KERNEL_TAIL
 KERNEL_HEAD(k_cndmask)   asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(b) : "vcc"); KERNEL_TAIL
+KERNEL_HEAD(k_cndmask_s)  { unsigned long long m = 0x5555555555555555ull ^ (unsigned long long)__builtin_amdgcn_readfirstlane(it);
+                          asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(b), "s"(m)); } KERNEL_TAIL
 KERNEL_HEAD(k_xor)       asm volatile("v_xor_b32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
 KERNEL_HEAD(k_sqrt)      asm volatile("v_sqrt_f32 %0, %0"        : "+v"(acc[i]));                    KERNEL_TAIL
 KERNEL_HEAD(k_rsq)       asm volatile("v_rsq_f32 %0, %0"         : "+v"(acc[i]));                    KERNEL_TAIL
@@ -64,6 +66,20 @@ KERNEL_HEAD(k_sin)       asm volatile("v_sin_f32 %0, %0"         : "+v"(acc[i]))
 KERNEL_HEAD(k_mul_lo)    asm volatile("v_mul_lo_u32 %0, %0, %1"  : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
 KERNEL_HEAD(k_mul_hi)    asm volatile("v_mul_hi_u32 %0, %0, %1"  : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
 KERNEL_HEAD(k_mad_u64)   asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(acc2[i]) : "v"(a), "v"(b) : "vcc"); KERNEL_TAIL
+KERNEL_HEAD(k_mul_u24)   asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_mulhi_u24) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(acc[i]) : "v"(b));        KERNEL_TAIL
+KERNEL_HEAD(k_mad_u24)   asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b)); KERNEL_TAIL
+KERNEL_HEAD(k_mov)       asm volatile("v_mov_b32 %0, %1"         : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_sub_vv)    asm volatile("v_sub_f32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_add_u32)   asm volatile("v_add_u32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_min_u32)   asm volatile("v_min_u32 %0, %0, %1"     : "+v"(acc[i]) : "v"(b));           KERNEL_TAIL
+KERNEL_HEAD(k_lshr)      asm volatile("v_lshrrev_b32 %0, 8, %0"  : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_alignbit)  asm volatile("v_alignbit_b32 %0, %0, %1, 9" : "+v"(acc[i]) : "v"(b));       KERNEL_TAIL
+KERNEL_HEAD(k_bitop3)    asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(acc[i]) : "v"(a), "v"(b)); KERNEL_TAIL
+KERNEL_HEAD(k_cvt_u32)   asm volatile("v_cvt_f32_u32 %0, %0"     : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_cmp_u32)   asm volatile("v_cmp_le_u32 vcc, %0, %1" : "+v"(acc[i]) : "v"(b) : "vcc");   KERNEL_TAIL
+KERNEL_HEAD(k_fract)     asm volatile("v_fract_f32 %0, %0"       : "+v"(acc[i]));                    KERNEL_TAIL
+KERNEL_HEAD(k_mul_f64)   asm volatile("v_mul_f64 %0, %0, %0"     : "+v"(acc2[i]));                   KERNEL_TAIL
 KERNEL_HEAD(k_fma_f64)   asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(acc2[i]));                   KERNEL_TAIL
 KERNEL_HEAD(k_add_f64)   asm volatile("v_add_f64 %0, %0, %0"     : "+v"(acc2[i]));                   KERNEL_TAIL
 KERNEL_HEAD(k_cvt_f64)   asm volatile("v_cvt_f64_f32 %0, %1"     : "+v"(acc2[i]) : "v"(b));          KERNEL_TAIL
@@ -85,8 +101,12 @@ int main() {
         {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4},
         {"v_pk_mul_f32 s,v", k_pk_mul_sv, 2}, {"v_pk_add_f32 s,v", k_pk_add_sv, 2},
         {"v_max_f32 v,v", k_max_vv, 1}, {"v_max3_f32 v,v,v", k_max3_vvv, 1}, {"v_cmp_ge_f32 v,v", k_cmp_vv, 1},
-        {"v_cndmask_b32", k_cndmask, 1}, {"v_xor_b32", k_xor, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1},
+        {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32 sgpr mask", k_cndmask_s, 1}, {"v_xor_b32", k_xor, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1},
         {"v_sin_f32", k_sin, 1}, {"v_mul_lo_u32", k_mul_lo, 1}, {"v_mul_hi_u32", k_mul_hi, 1}, {"v_mad_u64_u32", k_mad_u64, 1},
+        {"v_mul_u32_u24", k_mul_u24, 1}, {"v_mul_hi_u32_u24", k_mulhi_u24, 1}, {"v_mad_u32_u24", k_mad_u24, 1}, {"v_mov_b32", k_mov, 1},
+        {"v_sub_f32 v,v", k_sub_vv, 1}, {"v_add_u32", k_add_u32, 1}, {"v_min_u32", k_min_u32, 1}, {"v_lshrrev_b32", k_lshr, 1},
+        {"v_alignbit_b32", k_alignbit, 1}, {"v_bitop3_b32", k_bitop3, 1}, {"v_cvt_f32_u32", k_cvt_u32, 1}, {"v_cmp_le_u32", k_cmp_u32, 1},
+        {"v_fract_f32", k_fract, 1}, {"v_mul_f64", k_mul_f64, 1},
         {"v_fma_f64", k_fma_f64, 2}, {"v_add_f64", k_add_f64, 1}, {"v_cvt_f64_f32", k_cvt_f64, 1}, {"v_rsq_f64", k_rsq_f64, 1},
     };
     printf("%-20s %-6s %-9s %-9s %-12s\n", "form", "w/SIMD", "ms", "TFLOP/s", "Ginst/s/SIMD");
