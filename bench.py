@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the grid-search and 10k-sphere lines (N=1 only)")
     ap.add_argument("--launch-timeout", type=float, default=None,
                     help="seconds the parent waits for its ranks before it terminates them (default PT_BENCH_TIMEOUT or 1500)")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="with --gpus 1: join a ONE-rank RCCL process group and run the reduce, the barriers, the event timing and "
+                         "the gathers of the N > 1 path on the device (RCCL takes one rank per GPU, so a one-GPU box cannot run two); "
+                         "the line then carries `phases` like an N > 1 line")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control flow on ONE device: every rank renders on cuda:0 and the reduce goes "
                          "through gloo on host copies (RCCL refuses two ranks on one GPU); not a measurement")
@@ -371,6 +375,12 @@ def main():
     if os.environ.get("PT_BENCH_HANG_RANK") == os.environ.get("RANK", "0") and os.environ.get("PT_BENCH_CHILD"):
         time.sleep(3600)                          # fault injection: a rank that never reaches the rendezvous
 
+    # Rank 0's stdout carries ONE line, the result. Libraries print there too (RCCL its version banner at set-up, gloo a
+    # connection note): from here on file descriptor 1 is stderr's, and the result goes to the descriptor saved now.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -394,7 +404,10 @@ def main():
         # a launcher that gives every rank its own visible device (HIP_VISIBLE_DEVICES per rank) leaves one device, index 0
         local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-    ptd.init("gloo" if host_reduce else "nccl")   # "nccl" is RCCL; a single process needs no group
+    grouped = world > 1 or args.one_rank_group      # the collectives run (a one-rank group exercises the same calls)
+    if args.one_rank_group:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    ptd.init("gloo" if host_reduce else "nccl", force=args.one_rank_group)   # "nccl" is RCCL; a single process needs no group
 
     W, H, spp, depth = args.width, args.height, args.spp, args.depth
     if args.scaling == "weak":
@@ -433,7 +446,7 @@ def main():
         def step():
             accum.zero_()
             dev.render(W, H, spp_begin, spp_end, depth, 42, accum_ptr=accum.data_ptr())
-            if world == 1:
+            if not grouped:
                 return
             if host_reduce:
                 t_r = time.perf_counter()
@@ -447,13 +460,13 @@ def main():
                 # "wait for the slowest rank + the transfer" as this rank sees it.
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ptd.reduce_frame(accum, dst=0)
+                ptd.reduce_frame(accum, dst=0, force=args.one_rank_group)
                 e1.record()
                 reduce_marks.append((e0, e1))
 
         def fence():
             torch.cuda.synchronize()
-            if world > 1:
+            if grouped:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -475,7 +488,7 @@ def main():
     ktimes = dev.kernel_times() if dev else []
 
     phases = None
-    if world > 1:
+    if grouped:
         stat_dev = "cpu" if host_reduce else "cuda"
         own_dt = dt
         t = torch.tensor([dt], dtype=torch.float64, device=stat_dev)
@@ -496,13 +509,15 @@ def main():
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         tab = np.array([e.cpu().numpy() for e in every])
-        phases = {"kernel_ms_per_rank": [float(v) for v in tab[:, 0]],
-                  "kernel_ms_max_per_rank": [float(v) for v in tab[:, 1]],
-                  "reduce_ms_per_rank": [float(v) for v in tab[:, 2]],
-                  "step_ms_per_rank": [float(v) for v in tab[:, 3]],
+        num = lambda v: None if v != v else float(v)                     # NaN (nothing rendered: no kernel time) -> null
+        have_k = bool(np.isfinite(tab[:, 0]).any())
+        phases = {"kernel_ms_per_rank": [num(v) for v in tab[:, 0]],
+                  "kernel_ms_max_per_rank": [num(v) for v in tab[:, 1]],
+                  "reduce_ms_per_rank": [num(v) for v in tab[:, 2]],
+                  "step_ms_per_rank": [num(v) for v in tab[:, 3]],
                   "rays_per_rank": [int(v) for v in tab[:, 4]],
-                  "reduce_ms": float(tab[0, 2]),
-                  "max_rank_skew_ms": float(np.nanmax(tab[:, 0]) - np.nanmin(tab[:, 0])),
+                  "reduce_ms": num(tab[0, 2]),
+                  "max_rank_skew_ms": float(np.nanmax(tab[:, 0]) - np.nanmin(tab[:, 0])) if have_k else None,
                   "note": "means over the timed steps; kernel = k_render + k_tail (HIP events in the library); reduce = events on "
                           "the kernels' stream around dist.reduce (host path: wall clock incl. the copies), i.e. waiting for the "
                           "slowest rank plus the transfer; reduce_ms is rank 0's (the root); skew = max - min kernel_ms over ranks"}
@@ -565,6 +580,8 @@ def main():
             out["roofline"] = None
         elif host_reduce and world > 1:
             out["data"] = "synthetic; REHEARSAL on one GPU (all ranks on cuda:0, reduce through gloo on host copies): not a measurement"
+        if args.one_rank_group and not no_gpu:
+            out["data"] = "synthetic; one-rank RCCL group (--one-rank-group): the collectives of the N > 1 path on one device"
         if world == 1 and not args.no_extras and not no_gpu:
             try:
                 out["extras"] = extras(dev, host, accum, W, H, spp, depth, scene, cam)
@@ -575,8 +592,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
             except Exception as e:                                   # e.g. oracle/_build missing: the headline line still prints
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=result_out, flush=True)
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

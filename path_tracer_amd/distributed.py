@@ -38,9 +38,10 @@ def init(backend=None, force=False):
     return rank, local_rank, world
 
 
-def reduce_frame(accum, dst=0):
-    """Sum the per-rank accumulation buffers into rank `dst` (one message of W*H*3 floats)."""
+def reduce_frame(accum, dst=0, force=False):
+    """Sum the per-rank accumulation buffers into rank `dst` (one message of W*H*3 floats). force: also issue the
+    collective in a one-rank group (same call, nothing to add)."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum

@@ -53,6 +53,15 @@ def test_phases_and_efficiency_fields_of_a_two_rank_line():
     assert eff["source"] == "PT_BENCH_N1_MS" and abs(eff["efficiency"] - 1000.0 / out["ms_per_step"]) < 1e-6   # weak: ideal = the 1-GPU step
 
 
+def test_one_rank_group_runs_the_collective_code_of_the_n_rank_path():
+    p = subprocess.run([sys.executable, BENCH, "--one-rank-group"] + SMALL, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = _one_json_line(p.stdout)              # gloo's connection note (and RCCL's banner on a GPU) must not reach stdout
+    ph = out["phases"]
+    assert out["n_gpus"] == 1 and len(ph["step_ms_per_rank"]) == 1 and ph["reduce_ms"] >= 0
+    assert ph["kernel_ms_per_rank"] == [None] and ph["max_rank_skew_ms"] is None        # nothing was rendered: no kernel time
+
+
 def test_a_rank_that_dies_at_start_ends_the_launch_quickly():
     """Rank 1 exits with code 3 before the rendezvous: rank 0 would wait in init_process_group for minutes. The parent
     must notice, terminate rank 0, name the failed rank and return non-zero, in well under the backend's timeout."""
@@ -89,9 +98,7 @@ def test_bench_under_an_outside_launcher():
                         "--master-port", str(port), BENCH, "--gpus", "2"] + SMALL, env=_clean_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    out = _one_json_line(p.stdout)              # under an outside launcher too: nothing but the result on stdout
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["spp_per_gpu"] == 100
 
 

@@ -101,6 +101,26 @@ def test_bench_two_ranks_through_its_own_launcher():
     assert 2.0 < s["rays_per_sample"] < 3.2
 
 
+def test_bench_one_rank_rccl_group_on_the_device():
+    """bench.py's own N > 1 code (RCCL reduce of the device buffer between HIP events on the kernels' stream, barriers,
+    gathers of device tensors) with a one-rank group: the exact statements an 8-GPU run executes, on the one GPU there is."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-rank-group", "--steps", "3", "--warmup", "1", "--width", "640",
+                        "--height", "360", "--spp", "16", "--no-extras", "--no-cpu-baseline"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # RCCL's version banner goes to stderr, the result alone to stdout
+    out = json.loads(lines[0])
+    ph = out["phases"]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "one-rank RCCL group" in out["data"]
+    assert len(ph["kernel_ms_per_rank"]) == 1 and ph["kernel_ms_per_rank"][0] > 0
+    assert 0 <= ph["reduce_ms"] < ph["step_ms_per_rank"][0] and ph["rays_per_rank"][0] > 640 * 360 * 16 * 3
+    assert 0.2 < out["roofline"]["frac"] < 1.0
+
+
 _RCCL_ONE_RANK = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
