@@ -158,7 +158,9 @@ int pt_kernel_times_split(pt_handle h, float* out_ms, float* tail_ms, int cap, i
 int pt_reduce(pt_handle* handles, int n, int root);
 /* The RCCL library and the communicators are set up on the first pt_reduce and kept for the same device list
  * (destroyed when the list changes or the last handle goes). One handle per device; two handles on one device
- * are rejected. comm_inits = communicator set-ups made so far, cached_ranks = ranks of the set in use. */
+ * are rejected. comm_inits = communicator set-ups made so far, cached_ranks = ranks of the set in use.
+ * (Diagnostic: with PT_REDUCE_FORCE_RCCL=1 in the environment a ONE-handle pt_reduce, which otherwise returns at once,
+ * goes through a one-rank RCCL communicator: the way to run these calls on a machine with one GPU.) */
 int pt_reduce_stats(int* comm_inits, int* cached_ranks);
 
 /* ---- Unit-test entry points: the device functions of the sample loop, one call per batch. ---- */

@@ -1575,7 +1575,9 @@ int pt_reduce(pt_handle* handles, int n, int root) {
                 return fail(h0, PT_ERR_INVALID, "pt_reduce: two handles on device " + std::to_string(handles[i]->device) +
                                                     " (one handle per GPU: RCCL takes one rank per device)");
     }
-    if (n == 1) return 0;
+    // One handle: nothing to sum. (PT_REDUCE_FORCE_RCCL=1 goes through RCCL all the same, a one-rank communicator and an
+    // in-place reduce that leaves the buffer as it is: the only way to run this function's RCCL calls on a one-GPU machine.)
+    if (n == 1 && !(std::getenv("PT_REDUCE_FORCE_RCCL") && std::atoi(std::getenv("PT_REDUCE_FORCE_RCCL")) != 0)) return 0;
     std::lock_guard<std::mutex> lock(g_rccl.mutex);
     RcclState& R = g_rccl;
     if (!R.lib) {

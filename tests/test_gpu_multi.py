@@ -179,6 +179,28 @@ def test_pt_reduce_argument_checks_on_one_gpu():
         a.close(); b.close()
 
 
+def test_pt_reduce_through_rccl_with_one_rank(monkeypatch):
+    """pt_reduce's RCCL calls (librccl through dlopen, ncclCommInitAll, ncclReduce with the float32 / sum codes, group
+    start / end, the cached communicator) on the one GPU there is: PT_REDUCE_FORCE_RCCL=1 makes a one-handle reduce go
+    through a one-rank communicator instead of returning at once. The buffer must come back unchanged."""
+    from path_tracer_amd import Device, host
+    from path_tracer_amd._capi import reduce, reduce_stats
+    monkeypatch.setenv("PT_REDUCE_FORCE_RCCL", "1")
+    d = Device(0)
+    try:
+        d.set_scene(host.generate_scene(250, 1, 2)); d.set_camera(host.camera_setup())
+        W, H = 160, 90
+        before, _ = d.render_image(W, H, 3, 50, seed=5)
+        inits0, _ = reduce_stats()
+        reduce([d]); reduce([d])
+        inits, ranks = reduce_stats()
+        assert inits == inits0 + 1 and ranks == 1                  # set up once, re-used by the second call
+        after = d.read_accum(W, H)
+        assert before.any() and np.array_equal(after, before)
+    finally:
+        d.close()
+
+
 @pytest.mark.skipif(_n_devices() < 2, reason="pt_reduce sums over RCCL between two GPUs of this process")
 def test_pt_reduce_two_gpus_and_cached_communicators():
     from path_tracer_amd import Device, host
