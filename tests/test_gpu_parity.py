@@ -324,6 +324,41 @@ def test_round3_whole_path_kats_on_the_device(dev, kat):
     use(dev, host.generate_scene(250, 1, 2), host.camera_setup())
 
 
+def test_trace_edges(dev):
+    """pt_trace: an empty batch, depth 0 without a uniform array, bad arguments, and the call before any scene is set."""
+    from path_tracer_amd import Device, PtError, host
+    use(dev, host.generate_scene(250, 1, 2), host.camera_setup())
+    r = dev.trace(np.zeros((0, 3)), np.zeros((0, 3)), 5, np.zeros((0, 5, 3)))
+    assert r["rgb"].shape == (0, 3) and len(r["rays"]) == 0
+    r = dev.trace([[8, 2, 3]], [[-8, -2, -3]], 0, np.zeros((1, 0, 3)))
+    assert list(r["rgb"][0]) == [0, 0, 0] and r["rays"][0] == 0                     # Path Tracer.cpp:86
+    with pytest.raises(PtError, match="bad arguments"):
+        dev.trace([[0, 0, 0]], [[0, 0, -1]], -1, np.zeros((1, 0, 3)))
+    fresh = Device(0)
+    try:
+        with pytest.raises(PtError, match="set the scene first"):
+            fresh.trace([[0, 0, 0]], [[0, 0, -1]], 3, np.zeros((1, 3, 3)))
+    finally:
+        fresh.close()
+    # 1,000 copies of one ray give 1,000 identical answers (no cross-talk between the threads of a launch)
+    u = np.tile(np.array([[0.3, 0.6, 0.2]]), (1000, 50, 1))
+    r = dev.trace(np.tile([[8.0, 2.0, 3.0]], (1000, 1)), np.tile([[-8.0, -1.9, -3.0]], (1000, 1)), 50, u)
+    assert np.all(r["rgb"] == r["rgb"][0]) and np.all(r["rays"] == r["rays"][0]) and r["rays"][0] >= 2
+
+
+def test_set_scene_rejects_what_the_sums_cannot_hold(dev):
+    """A negative or non-finite albedo is refused at pt_set_scene (the fixed-point sums hold non-negative radiance only)."""
+    from path_tracer_amd import PtError, host
+    sc = host.generate_scene(10, 1, 2)
+    for bad in (-0.1, float("nan"), float("inf")):
+        sc2 = {k: np.array(v, copy=True) for k, v in sc.items()}
+        i = int(np.flatnonzero(sc2["kind"] != 2)[0])
+        sc2["ag"][i] = bad
+        with pytest.raises(PtError, match="albedo"):
+            dev.set_scene(sc2)
+    use(dev, host.generate_scene(250, 1, 2), host.camera_setup())
+
+
 def test_trace_against_the_oracle_on_random_paths(dev, orc):
     """pt_trace against orc_trace on the 505-sphere scene: camera-like rays with random injected uniforms. Paths whose
     discrete decisions agree (same ray count) must agree in colour to fp32 accuracy; a few may flip a decision in fp32."""
