@@ -361,7 +361,7 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
     // 16 lanes is a DPP row: the other lane's value comes through a row rotation inside the vector ALU (round 3; the
     // cross-lane shuffles this replaces went through the LDS crossbar, two round trips of its latency per step, in the
     // dependent chain of every bounce of the frame's longest path).
-    if constexpr (G == 16) {
+    if constexpr (G == 16 || G == 64) {
 #define PT_ROR_STEP(CTRL)                                                                                                  \
         {                                                                                                                  \
             const float ot = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(best_d), CTRL, 0xf, 0xf, false)); \
@@ -372,6 +372,24 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
         }
         PT_ROR_STEP(0x128) PT_ROR_STEP(0x124) PT_ROR_STEP(0x122) PT_ROR_STEP(0x121)      // row_ror:8, 4, 2, 1
 #undef PT_ROR_STEP
+        if constexpr (G == 64) {
+            // the whole wave holds one ray (every lane enabled): each of the four rows now has its best in all its lanes;
+            // they meet through scalar registers (v_readlane of lanes 0, 16, 32, 48), no trip through LDS, and every
+            // lane folds the four in the same order
+            float rt[4]; int ri[4];
+#pragma unroll
+            for (int row = 0; row < 4; ++row) {
+                rt[row] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best_d), 16 * row));
+                ri[row] = __builtin_amdgcn_readlane(best_i, 16 * row);
+            }
+            best_d = rt[0]; best_i = ri[0];
+#pragma unroll
+            for (int row = 1; row < 4; ++row) {
+                const bool take = (rt[row] < best_d) | ((rt[row] == best_d) & (ri[row] > best_i));
+                best_d = take ? rt[row] : best_d;
+                best_i = take ? ri[row] : best_i;
+            }
+        }
     } else {
 #pragma unroll
         for (int s = G / 2; s > 0; s >>= 1) {

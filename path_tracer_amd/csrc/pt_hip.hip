@@ -163,12 +163,25 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
             pc_first = -(1 << 30);                                        // the philox blocks held are another path's
             active = true;
         }
-        if (!__any(active)) break;                                        // (waves leave independently: no barrier in here)
+        const unsigned long long with_path = __ballot(active);
+        if (with_path == 0ull) break;                                     // (waves leave independently: no barrier in here)
         if (iterations) ++*iterations;                                    // (the per-wave timing build only)
+        // ONE path left in this wave (the end of a frame is a few long paths, each alone in its wave): all 64 lanes share
+        // out its spheres, a quarter of the quads per lane and of the round trips to the records. The other lanes fetch
+        // the ray from the group that holds it; the answer is the same in every lane (same arithmetic per sphere, same rule).
+        float bt = 0.0f; int bi = -1;
+        const bool alone = G < 64 && __popcll(with_path) == G;
+        if (alone) {                                                      // wave-uniform; every lane takes part
+            const int holder = __ffsll(with_path) - 1;
+            const f3 so = mk3(__shfl(o.x, holder), __shfl(o.y, holder), __shfl(o.z, holder));
+            const f3 sd = mk3(__shfl(dh.x, holder), __shfl(dh.y, holder), __shfl(dh.z, holder));
+            const float sl = __shfl(len, holder), ss = __shfl(self_t, holder);
+            const int sp = __shfl(prev, holder);
+            coop_scan<64>(quads, P.scene.n_pad, tid & 63, so, sd, 0.001f * sl, sp, ss, bt, bi);
+        }
         if (active) {
             if (sub == 0) ++rays;
-            float bt; int bi;
-            coop_scan<G>(quads, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+            if (!alone) coop_scan<G>(quads, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 if (sub == 0) {
