@@ -317,79 +317,94 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
     float best_d = __builtin_inff();
     best_i = -1;
     const int n_quads = n_pad >> 2;
-    constexpr int CHUNK = 32;                                            // quads per lane and chunk: one bit each
-    for (int q0 = sub; q0 < n_quads; q0 += G * CHUNK) {                  // (the lanes of a wave differ in `sub` only: same trip count +- 1)
-        // phase 1: which of my quads does the line meet?
-        uint32_t noted = 0u;
-        for (int i = 0; i < CHUNK && q0 + G * i < n_quads; ++i) {
+    // the roots of quad q's four spheres from tier 1's b and U: the arithmetic of tier2, operation for operation
+    auto roots = [&](int q, const v2f (&B)[2], const v2f (&U)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int j = 4 * q + 2 * h + k;
+                const float s = fast_sqrt(U[h][k] - pp);                   // NaN for a line that misses: its bits are above +inf's
+                const float bp = B[h][k] - tmin;
+                const float t1 = bp - s, t2 = bp + s;
+                const uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
+                const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));   // j rises within a lane: <= keeps the later index
+                best_d = ok ? __uint_as_float(tu) : best_d;
+                best_i = ok ? j : best_i;
+            }
+        }
+    };
+    if (G == 64 && n_quads <= 2 * G) {
+        // A whole wave on one ray and a quad or two per lane: one pass, the roots straight from tier 1's registers where
+        // the line meets a sphere of the quad (some lane's does in nearly every pass: two phases would only read and
+        // compute the same quads twice).
+        for (int q = sub; q < n_quads; q += G) {
             float R[16];
-            recs.quad(q0 + G * i, R);
+            recs.quad(q, R);
             v2f B[2], U[2];
             coop_tier1(R, dh, ne, p2, B, U);
             const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
-            noted |= (m >= pp ? 1u : 0u) << i;
+            if (m >= pp) roots(q, B, U);
         }
-        // phase 2: the roots, for the noted quads only
-        while (__any(noted != 0u)) {
-            if (noted != 0u) {
-                const int i = __builtin_ctz(noted);
-                noted &= noted - 1u;
-                const int q = q0 + G * i;
+    } else {
+        constexpr int CHUNK = 32;                                        // quads per lane and chunk: one bit each
+        for (int q0 = sub; q0 < n_quads; q0 += G * CHUNK) {              // (the lanes of a wave differ in `sub` only: same trip count +- 1)
+            // phase 1: which of my quads does the line meet?
+            uint32_t noted = 0u;
+            for (int i = 0; i < CHUNK && q0 + G * i < n_quads; ++i) {
                 float R[16];
-                recs.quad(q, R);
+                recs.quad(q0 + G * i, R);
                 v2f B[2], U[2];
                 coop_tier1(R, dh, ne, p2, B, U);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int j = 4 * q + 2 * h + k;
-                        const float s = fast_sqrt(U[h][k] - pp);           // NaN for a line that misses: its bits are above +inf's
-                        const float bp = B[h][k] - tmin;                   // the arithmetic of tier2, operation for operation
-                        const float t1 = bp - s, t2 = bp + s;
-                        const uint32_t tu = min(__float_as_uint(t1), __float_as_uint(t2));
-                        const bool ok = (j != prev) & (tu <= __float_as_uint(best_d));   // j rises within a lane: <= keeps the later index
-                        best_d = ok ? __uint_as_float(tu) : best_d;
-                        best_i = ok ? j : best_i;
-                    }
+                const float m = __builtin_fmaxf(__builtin_fmaxf(U[0].x, U[0].y), __builtin_fmaxf(U[1].x, U[1].y));
+                noted |= (m >= pp ? 1u : 0u) << i;
+            }
+            // phase 2: the roots, for the noted quads only
+            while (__any(noted != 0u)) {
+                if (noted != 0u) {
+                    const int i = __builtin_ctz(noted);
+                    noted &= noted - 1u;
+                    const int q = q0 + G * i;
+                    float R[16];
+                    recs.quad(q, R);
+                    v2f B[2], U[2];
+                    coop_tier1(R, dh, ne, p2, B, U);
+                    roots(q, B, U);
                 }
             }
         }
     }
-    // The group's closest hit, in every lane of the group. "Smaller t, then larger index" is a total order, so combining
-    // each lane with the lane 8, 4, 2 and 1 places around the group's ring leaves the group's best everywhere. A group of
-    // 16 lanes is a DPP row: the other lane's value comes through a row rotation inside the vector ALU (round 3; the
-    // cross-lane shuffles this replaces went through the LDS crossbar, two round trips of its latency per step, in the
-    // dependent chain of every bounce of the frame's longest path).
+    // The group's closest hit, in every lane of the group. "Smaller t, then larger index" is a total order: first the
+    // group's smallest t (bit patterns of non-negative floats and +inf order like unsigned integers, as in the roots above),
+    // then the largest index among the lanes that hold that t (-1: no hit, or not this lane's). A group of 16 lanes is a
+    // DPP row: each of the four steps of either reduction is ONE instruction, a minimum or maximum whose second operand
+    // comes through a row rotation (row_ror:8, 4, 2, 1) inside the vector ALU. (Round 3. The first version went through
+    // the LDS crossbar, two round trips per step; the second compared (t, index) pairs, nine instructions per step; all
+    // in the dependent chain of every bounce of the frame's longest path.)
     if constexpr (G == 16 || G == 64) {
-#define PT_ROR_STEP(CTRL)                                                                                                  \
-        {                                                                                                                  \
-            const float ot = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(best_d), CTRL, 0xf, 0xf, false)); \
-            const int oi = __builtin_amdgcn_update_dpp(0, best_i, CTRL, 0xf, 0xf, false);                                  \
-            const bool take = (ot < best_d) | ((ot == best_d) & (oi > best_i));                                            \
-            best_d = take ? ot : best_d;                                                                                   \
-            best_i = take ? oi : best_i;                                                                                   \
-        }
-        PT_ROR_STEP(0x128) PT_ROR_STEP(0x124) PT_ROR_STEP(0x122) PT_ROR_STEP(0x121)      // row_ror:8, 4, 2, 1
-#undef PT_ROR_STEP
+        const uint32_t mine = __float_as_uint(best_d);
+        uint32_t m = mine;
+#define PT_ROR_MIN(CTRL) m = min(m, uint32_t(__builtin_amdgcn_update_dpp(int(0xffffffffu), int(m), CTRL, 0xf, 0xf, false)));
+        PT_ROR_MIN(0x128) PT_ROR_MIN(0x124) PT_ROR_MIN(0x122) PT_ROR_MIN(0x121)
+#undef PT_ROR_MIN
         if constexpr (G == 64) {
-            // the whole wave holds one ray (every lane enabled): each of the four rows now has its best in all its lanes;
-            // they meet through scalar registers (v_readlane of lanes 0, 16, 32, 48), no trip through LDS, and every
-            // lane folds the four in the same order
-            float rt[4]; int ri[4];
-#pragma unroll
-            for (int row = 0; row < 4; ++row) {
-                rt[row] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best_d), 16 * row));
-                ri[row] = __builtin_amdgcn_readlane(best_i, 16 * row);
-            }
-            best_d = rt[0]; best_i = ri[0];
-#pragma unroll
-            for (int row = 1; row < 4; ++row) {
-                const bool take = (rt[row] < best_d) | ((rt[row] == best_d) & (ri[row] > best_i));
-                best_d = take ? rt[row] : best_d;
-                best_i = take ? ri[row] : best_i;
-            }
+            // the whole wave holds one ray (every lane enabled): each of the four rows has its minimum in all its lanes;
+            // they meet through scalar registers (v_readlane of lanes 0, 16, 32, 48), no trip through LDS
+            const uint32_t r0 = __builtin_amdgcn_readlane(int(m), 0), r1 = __builtin_amdgcn_readlane(int(m), 16);
+            const uint32_t r2 = __builtin_amdgcn_readlane(int(m), 32), r3 = __builtin_amdgcn_readlane(int(m), 48);
+            m = min(min(r0, r1), min(r2, r3));
         }
+        int ci = mine == m ? best_i : -1;
+#define PT_ROR_MAX(CTRL) ci = max(ci, __builtin_amdgcn_update_dpp(int(0x80000000u), ci, CTRL, 0xf, 0xf, false));
+        PT_ROR_MAX(0x128) PT_ROR_MAX(0x124) PT_ROR_MAX(0x122) PT_ROR_MAX(0x121)
+#undef PT_ROR_MAX
+        if constexpr (G == 64) {
+            const int r0 = __builtin_amdgcn_readlane(ci, 0), r1 = __builtin_amdgcn_readlane(ci, 16);
+            const int r2 = __builtin_amdgcn_readlane(ci, 32), r3 = __builtin_amdgcn_readlane(ci, 48);
+            ci = max(max(r0, r1), max(r2, r3));
+        }
+        best_d = __uint_as_float(m);
+        best_i = ci;
     } else {
 #pragma unroll
         for (int s = G / 2; s > 0; s >>= 1) {

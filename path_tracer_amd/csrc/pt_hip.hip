@@ -129,6 +129,12 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
     bank[lane * 3 + 0] = zero; bank[lane * 3 + 1] = zero; bank[lane * 3 + 2] = zero;
 }
 
+#ifdef PT_WAVEPROF
+#ifndef PT_SECPROF_AFTER
+#define PT_SECPROF_AFTER 10000     // count the bounces that start this long (10 ns units) after the wave did: the others share their SIMD with busy waves
+#endif
+__device__ unsigned long long g_sprof[8];     // sections of the bounces a path has a wave to itself: [0] bounces, [1] scan, [2] finish, [3] scatter (10 ns units)
+#endif
 // Finishes the paths in slots[0 .. n_slots) (bounce < 0: empty slot), a path per GROUP of G lanes: the lanes of a group hold
 // the same path and share out the spheres (coop_scan); same arithmetic per sphere, same hit rule, same philox blocks and
 // integer sums straight to the frame as the sample loop, so the frame is bit for bit what the loop alone would produce. The
@@ -148,6 +154,10 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
     uint32_t pixel = 0, sample = 0, top_pixel = 0;
     u4 pc; pc.x = pc.y = pc.z = pc.w = 0u;                                // philox block of bounce pc_first + sub of the group's path
     int pc_first = -(1 << 30);
+#ifdef PT_WAVEPROF
+    unsigned long long sec_n = 0, sec_a = 0, sec_b = 0, sec_c = 0;
+    const unsigned long long sec_start = wall_clock64();
+#endif
     for (;;) {
         // a group without a path takes the next occupied slot (the lanes of a group read the same words)
         while (!active && more) {
@@ -171,17 +181,26 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
         // the ray from the group that holds it; the answer is the same in every lane (same arithmetic per sphere, same rule).
         float bt = 0.0f; int bi = -1;
         const bool alone = G < 64 && __popcll(with_path) == G;
+#ifdef PT_WAVEPROF
+        const unsigned long long sp0 = wall_clock64();
+        unsigned long long sp1 = sp0, sp2 = sp0;
+#endif
         if (alone) {                                                      // wave-uniform; every lane takes part
-            const int holder = __ffsll(with_path) - 1;
-            const f3 so = mk3(__shfl(o.x, holder), __shfl(o.y, holder), __shfl(o.z, holder));
-            const f3 sd = mk3(__shfl(dh.x, holder), __shfl(dh.y, holder), __shfl(dh.z, holder));
-            const float sl = __shfl(len, holder), ss = __shfl(self_t, holder);
-            const int sp = __shfl(prev, holder);
+            const int holder = __ffsll(with_path) - 1;                    // wave-uniform: the ray comes through scalar registers
+            auto from_holder = [holder](float v) { return __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(v)), holder))); };
+            const f3 so = mk3(from_holder(o.x), from_holder(o.y), from_holder(o.z));
+            const f3 sd = mk3(from_holder(dh.x), from_holder(dh.y), from_holder(dh.z));
+            const float sl = from_holder(len), ss = from_holder(self_t);
+            const int sp = __builtin_amdgcn_readlane(prev, holder);
             coop_scan<64>(quads, P.scene.n_pad, tid & 63, so, sd, 0.001f * sl, sp, ss, bt, bi);
         }
         if (active) {
             if (sub == 0) ++rays;
             if (!alone) coop_scan<G>(quads, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
+#ifdef PT_WAVEPROF
+            asm volatile("" :: "v"(bt), "v"(bi));
+            sp1 = sp2 = wall_clock64();
+#endif
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
                 if (sub == 0) {
@@ -197,6 +216,10 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
                 const GeomRec g = geom[bi];
                 const MatRec mat = mats[bi];
                 const HitRec h = finish_hit(g, bi == prev, o, dh, 0.001 * double(len));
+#ifdef PT_WAVEPROF
+                asm volatile("" :: "v"(h.p.x), "v"(h.n.x), "v"(h.n.z));
+                sp2 = wall_clock64();
+#endif
                 prev = bi;
                 ++bounce;
                 if (bounce >= P.max_depth) {                                         // Path Tracer.cpp:86
@@ -222,8 +245,18 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
                     active = ok;                                                     // Path Tracer.cpp:100 -> black
                 }
             }
+#ifdef PT_WAVEPROF
+            if (alone && sub == 0) {
+                asm volatile("" :: "v"(dh.x), "v"(self_t), "v"(len));
+                const unsigned long long sp3 = wall_clock64();
+                if (sp0 - sec_start > PT_SECPROF_AFTER) { ++sec_n; sec_a += sp1 - sp0; sec_b += sp2 - sp1; sec_c += sp3 - sp2; }
+            }
+#endif
         }
     }
+#ifdef PT_WAVEPROF
+    if (sec_n) { atomicAdd(&g_sprof[0], sec_n); atomicAdd(&g_sprof[1], sec_a); atomicAdd(&g_sprof[2], sec_b); atomicAdd(&g_sprof[3], sec_c); }
+#endif
     return rays;
 }
 
@@ -1476,6 +1509,14 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
             stage_end = std::max(stage_end, st[4 * w + 1]); loop_end = std::max(loop_end, st[4 * w + 2]);
             it_max = std::max(it_max, st[4 * w + 3]); it_sum += st[4 * w + 3]; busy += st[4 * w + 3] ? 1 : 0;
             stage_sum += double(st[4 * w + 1] - st[4 * w]); loop_sum += double(st[4 * w + 2] - st[4 * w + 1]);
+        }
+        {
+            unsigned long long sp[8];
+            PT_HIP(h, hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_sprof), sizeof(sp)));
+            if (sp[0]) fprintf(stderr, "[tail prof] a path alone in its wave: %llu bounces, per bounce scan %.0f ns, finish %.0f ns, scatter %.0f ns\n", sp[0],
+                               10.0 * sp[1] / sp[0], 10.0 * sp[2] / sp[0], 10.0 * sp[3] / sp[0]);
+            unsigned long long z[8] = {0};
+            PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)));
         }
         fprintf(stderr, "[tail prof] waves %zu (with a path %llu): last start +%.1f us, last staged +%.1f us (mean staging %.1f), last loop end +%.1f us (mean loop %.1f us), iterations max %llu mean %.2f\n",
                 nw, busy, (last_start - t0) / 100.0, (stage_end - t0) / 100.0, stage_sum / nw / 100.0, (loop_end - t0) / 100.0, loop_sum / nw / 100.0, it_max, double(it_sum) / nw);
