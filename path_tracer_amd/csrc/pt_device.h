@@ -381,11 +381,12 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
     // comes through a row rotation (row_ror:8, 4, 2, 1) inside the vector ALU. (Round 3. The first version went through
     // the LDS crossbar, two round trips per step; the second compared (t, index) pairs, nine instructions per step; all
     // in the dependent chain of every bounce of the frame's longest path.)
-    if constexpr (G == 16 || G == 64) {
+    if constexpr (G == 4 || G == 16 || G == 64) {
         const uint32_t mine = __float_as_uint(best_d);
         uint32_t m = mine;
 #define PT_ROR_MIN(CTRL) m = min(m, uint32_t(__builtin_amdgcn_update_dpp(int(0xffffffffu), int(m), CTRL, 0xf, 0xf, false)));
-        PT_ROR_MIN(0x128) PT_ROR_MIN(0x124) PT_ROR_MIN(0x122) PT_ROR_MIN(0x121)
+        if constexpr (G == 4) { PT_ROR_MIN(0xb1) PT_ROR_MIN(0x4e) }     // a group of four lanes: quad_perm:[1,0,3,2], then [2,3,0,1]
+        else { PT_ROR_MIN(0x128) PT_ROR_MIN(0x124) PT_ROR_MIN(0x122) PT_ROR_MIN(0x121) }
 #undef PT_ROR_MIN
         if constexpr (G == 64) {
             // the whole wave holds one ray (every lane enabled): each of the four rows has its minimum in all its lanes;
@@ -396,7 +397,8 @@ PT_DEV void coop_scan(const Quads& recs, int n_pad, int sub, f3 o, f3 dh, float 
         }
         int ci = mine == m ? best_i : -1;
 #define PT_ROR_MAX(CTRL) ci = max(ci, __builtin_amdgcn_update_dpp(int(0x80000000u), ci, CTRL, 0xf, 0xf, false));
-        PT_ROR_MAX(0x128) PT_ROR_MAX(0x124) PT_ROR_MAX(0x122) PT_ROR_MAX(0x121)
+        if constexpr (G == 4) { PT_ROR_MAX(0xb1) PT_ROR_MAX(0x4e) }
+        else { PT_ROR_MAX(0x128) PT_ROR_MAX(0x124) PT_ROR_MAX(0x122) PT_ROR_MAX(0x121) }
 #undef PT_ROR_MAX
         if constexpr (G == 64) {
             const int r0 = __builtin_amdgcn_readlane(ci, 0), r1 = __builtin_amdgcn_readlane(ci, 16);

@@ -133,7 +133,8 @@ PT_DEV void flush_bank(const RenderParams& P, unsigned long long* bank, int tx, 
 #ifndef PT_SECPROF_AFTER
 #define PT_SECPROF_AFTER 10000     // count the bounces that start this long (10 ns units) after the wave did: the others share their SIMD with busy waves
 #endif
-__device__ unsigned long long g_sprof[8];     // sections of the bounces a path has a wave to itself: [0] bounces, [1] scan, [2] finish, [3] scatter (10 ns units)
+__device__ unsigned long long g_tprof2[8192 * 2];   // per wave of k_tail: 10 ns units spent in iterations with one path, with several
+__device__ unsigned long long g_sprof[16];     // sections of the bounces a path has a wave to itself: [0] bounces, [1] scan, [2] finish, [3] scatter (10 ns units)
 #endif
 // Finishes the paths in slots[0 .. n_slots) (bounce < 0: empty slot), a path per GROUP of G lanes: the lanes of a group hold
 // the same path and share out the spheres (coop_scan); same arithmetic per sphere, same hit rule, same philox blocks and
@@ -155,9 +156,20 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
     u4 pc; pc.x = pc.y = pc.z = pc.w = 0u;                                // philox block of bounce pc_first + sub of the group's path
     int pc_first = -(1 << 30);
 #ifdef PT_WAVEPROF
-    unsigned long long sec_n = 0, sec_a = 0, sec_b = 0, sec_c = 0;
-    const unsigned long long sec_start = wall_clock64();
+    __shared__ unsigned long long sec_lds[4][12];                         // this wave's sums (one lane adds to them; registers would cost the build a third of its waves)
+    unsigned long long* const sec = sec_lds[(tid >> 6) & 3];
+    if ((tid & 63) < 12) sec[tid & 63] = 0;
+    const uint32_t sec_start = uint32_t(wall_clock64());
 #endif
+    auto take_slot = [&](int take) {
+        const TailPath tp = slots[take];
+        if (tp.bounce < 0) return;
+        o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
+        len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
+        pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
+        pc_first = -(1 << 30);                                            // the philox blocks held are another path's
+        active = true;
+    };
     for (;;) {
         // a group without a path takes the next occupied slot (the lanes of a group read the same words)
         while (!active && more) {
@@ -165,25 +177,20 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
             if (sub == 0) take = atomicAdd(next, 1);
             take = __shfl(take, tid & 63 & ~(G - 1));
             if (take >= n_slots) { more = false; break; }
-            const TailPath tp = slots[take];
-            if (tp.bounce < 0) continue;
-            o = mk3(tp.o[0], tp.o[1], tp.o[2]); dh = mk3(tp.dh[0], tp.dh[1], tp.dh[2]); thr = mk3(tp.thr[0], tp.thr[1], tp.thr[2]);
-            len = tp.len; self_t = tp.self_t; prev = tp.prev; bounce = tp.bounce;
-            pixel = tp.pixel; sample = tp.sample; top_pixel = tp.top_pixel;
-            pc_first = -(1 << 30);                                        // the philox blocks held are another path's
-            active = true;
+            take_slot(take);
         }
         const unsigned long long with_path = __ballot(active);
         if (with_path == 0ull) break;                                     // (waves leave independently: no barrier in here)
-        if (iterations) ++*iterations;                                    // (the per-wave timing build only)
+        if (iterations) *iterations += 1ull + ((G < 64 && __popcll(with_path) == G) ? (1ull << 20) : 0ull);   // (the per-wave timing build only; alone-mode iterations in the upper bits)
         // ONE path left in this wave (the end of a frame is a few long paths, each alone in its wave): all 64 lanes share
         // out its spheres, a quarter of the quads per lane and of the round trips to the records. The other lanes fetch
         // the ray from the group that holds it; the answer is the same in every lane (same arithmetic per sphere, same rule).
         float bt = 0.0f; int bi = -1;
-        const bool alone = G < 64 && __popcll(with_path) == G;
+        const int n_paths = __popcll(with_path) / G;
+        const bool alone = G < 64 && n_paths == 1;
 #ifdef PT_WAVEPROF
-        const unsigned long long sp0 = wall_clock64();
-        unsigned long long sp1 = sp0, sp2 = sp0;
+        const uint32_t sp0 = uint32_t(wall_clock64());                  // (32 bits: the differences are what is used)
+        uint32_t sp1 = sp0, sp2 = sp0;
 #endif
         if (alone) {                                                      // wave-uniform; every lane takes part
             const int holder = __ffsll(with_path) - 1;                    // wave-uniform: the ray comes through scalar registers
@@ -199,7 +206,7 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
             if (!alone) coop_scan<G>(quads, P.scene.n_pad, sub, o, dh, 0.001f * len, prev, self_t, bt, bi);
 #ifdef PT_WAVEPROF
             asm volatile("" :: "v"(bt), "v"(bi));
-            sp1 = sp2 = wall_clock64();
+            sp1 = sp2 = uint32_t(wall_clock64());
 #endif
             if (bi < 0) {                                                            // Path Tracer.cpp:105-107
                 const f3 c = thr * sky(dh.y);
@@ -218,7 +225,7 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
                 const HitRec h = finish_hit(g, bi == prev, o, dh, 0.001 * double(len));
 #ifdef PT_WAVEPROF
                 asm volatile("" :: "v"(h.p.x), "v"(h.n.x), "v"(h.n.z));
-                sp2 = wall_clock64();
+                sp2 = uint32_t(wall_clock64());
 #endif
                 prev = bi;
                 ++bounce;
@@ -246,16 +253,24 @@ PT_DEV unsigned int finish_paths(const RenderParams& P, const TailPath* slots, i
                 }
             }
 #ifdef PT_WAVEPROF
-            if (alone && sub == 0) {
+            if (sub == 0) {
                 asm volatile("" :: "v"(dh.x), "v"(self_t), "v"(len));
-                const unsigned long long sp3 = wall_clock64();
-                if (sp0 - sec_start > PT_SECPROF_AFTER) { ++sec_n; sec_a += sp1 - sp0; sec_b += sp2 - sp1; sec_c += sp3 - sp2; }
+                const uint32_t sp3 = uint32_t(wall_clock64());
+                if ((tid & 63) == __ffsll(with_path) - 1) sec[alone ? 9 : 10] += sp3 - sp0;        // every iteration of the wave, by kind
+                if (sp0 - sec_start > PT_SECPROF_AFTER) {
+                    if (alone) { sec[0] += 1; sec[1] += sp1 - sp0; sec[2] += sp2 - sp1; sec[3] += sp3 - sp2; }
+                    else if ((tid & 63) == __ffsll(with_path) - 1) { sec[4] += 1; sec[5] += sp1 - sp0; sec[6] += sp2 - sp1; sec[7] += sp3 - sp2; sec[8] += __popcll(with_path) / G; }
+                }
             }
 #endif
         }
     }
 #ifdef PT_WAVEPROF
-    if (sec_n) { atomicAdd(&g_sprof[0], sec_n); atomicAdd(&g_sprof[1], sec_a); atomicAdd(&g_sprof[2], sec_b); atomicAdd(&g_sprof[3], sec_c); }
+    if ((tid & 63) < 9 && sec[tid & 63]) atomicAdd(&g_sprof[tid & 63], sec[tid & 63]);
+    {
+        const unsigned w = blockIdx.x * 4 + (tid >> 6);
+        if ((tid & 63) < 2 && w < 8192) g_tprof2[2 * w + (tid & 63)] = sec[9 + (tid & 63)];
+    }
 #endif
     return rays;
 }
@@ -622,7 +637,11 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 __device__ unsigned long long g_tprof[8192 * 4 + 8];
 #endif
 template <bool LDS>
-__global__ void __launch_bounds__(256) k_tail(const RenderParams P) {
+__global__ void __launch_bounds__(256)
+#ifdef PT_WAVEPROF
+__attribute__((amdgpu_waves_per_eu(6, 6)))      // the timing build keeps the occupancy of the product build (its extra registers would cost a wave)
+#endif
+k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
 #ifdef PT_WAVEPROF
     const unsigned long long tp_start = wall_clock64();
@@ -1507,16 +1526,35 @@ int pt_render(pt_handle h, int width, int height, int spp_begin, int spp_end, in
         for (size_t w = 0; w < nw; ++w) {
             t0 = std::min(t0, st[4 * w]); last_start = std::max(last_start, st[4 * w]);
             stage_end = std::max(stage_end, st[4 * w + 1]); loop_end = std::max(loop_end, st[4 * w + 2]);
-            it_max = std::max(it_max, st[4 * w + 3]); it_sum += st[4 * w + 3]; busy += st[4 * w + 3] ? 1 : 0;
+            it_max = std::max(it_max, st[4 * w + 3] & 0xfffff); it_sum += st[4 * w + 3] & 0xfffff; busy += st[4 * w + 3] ? 1 : 0;
             stage_sum += double(st[4 * w + 1] - st[4 * w]); loop_sum += double(st[4 * w + 2] - st[4 * w + 1]);
         }
         {
-            unsigned long long sp[8];
+            unsigned long long sp[16];
             PT_HIP(h, hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_sprof), sizeof(sp)));
+            if (sp[4]) fprintf(stderr, "[tail prof] late iterations of waves with several paths (%.2f on average): %llu, per iteration scan %.0f ns, finish %.0f ns, scatter %.0f ns\n",
+                               double(sp[8]) / sp[4], sp[4], 10.0 * sp[5] / sp[4], 10.0 * sp[6] / sp[4], 10.0 * sp[7] / sp[4]);
             if (sp[0]) fprintf(stderr, "[tail prof] a path alone in its wave: %llu bounces, per bounce scan %.0f ns, finish %.0f ns, scatter %.0f ns\n", sp[0],
                                10.0 * sp[1] / sp[0], 10.0 * sp[2] / sp[0], 10.0 * sp[3] / sp[0]);
-            unsigned long long z[8] = {0};
+            unsigned long long z[16] = {0};
             PT_HIP(h, hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof(z)));
+        }
+        {
+            std::vector<double> le;
+            for (size_t w = 0; w < nw; ++w) if (st[4 * w + 3]) le.push_back(double(st[4 * w + 2] - t0) / 100.0);
+            std::sort(le.begin(), le.end());
+            auto q = [&](double f) { return le.empty() ? 0.0 : le[size_t(f * (le.size() - 1))]; };
+            std::vector<std::pair<unsigned long long, size_t>> ends;
+            for (size_t w = 0; w < nw; ++w) ends.push_back({st[4 * w + 2], w});
+            std::sort(ends.rbegin(), ends.rend());
+            static std::vector<unsigned long long> st2(8192 * 2);
+            PT_HIP(h, hipMemcpyFromSymbol(st2.data(), HIP_SYMBOL(g_tprof2), st2.size() * 8));
+            for (size_t k = 0; k < std::min<size_t>(4, ends.size()); ++k) {
+                const size_t w = ends[k].second;
+                fprintf(stderr, "[tail prof] one of the last waves: started +%.1f us, left +%.1f us, %llu iterations, %llu of them with one path (%.1f us; the others %.1f us)\n",
+                        (st[4 * w] - t0) / 100.0, (st[4 * w + 2] - t0) / 100.0, st[4 * w + 3] & 0xfffff, st[4 * w + 3] >> 20, st2[2 * w] / 100.0, st2[2 * w + 1] / 100.0);
+            }
+            fprintf(stderr, "[tail prof] waves leave at (10/50/90/99/99.9 %%/max) %.0f %.0f %.0f %.0f %.0f %.0f us\n", q(0.1), q(0.5), q(0.9), q(0.99), q(0.999), q(1.0));
         }
         fprintf(stderr, "[tail prof] waves %zu (with a path %llu): last start +%.1f us, last staged +%.1f us (mean staging %.1f), last loop end +%.1f us (mean loop %.1f us), iterations max %llu mean %.2f\n",
                 nw, busy, (last_start - t0) / 100.0, (stage_end - t0) / 100.0, stage_sum / nw / 100.0, (loop_end - t0) / 100.0, loop_sum / nw / 100.0, it_max, double(it_sum) / nw);
