@@ -11,7 +11,8 @@ B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 PMC1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 PMC2="SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_F32 SQ_WAVES_EQ_64"
 rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_pmc* gpurun_out/${tag}_g*
-timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_stats.log 2>&1
+# (the kernel-time pass runs more launches: the first launch of a process is 8 % slower than the others and would weigh a quarter)
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-extras > gpurun_out/${tag}_stats.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc $PMC1 --output-format csv -d gpurun_out/${tag}_pmc1 -- $B > gpurun_out/${tag}_pmc1.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc $PMC2 --output-format csv -d gpurun_out/${tag}_pmc2 -- $B > gpurun_out/${tag}_pmc2.log 2>&1
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc3 -- $B > gpurun_out/${tag}_pmc3.log 2>&1
