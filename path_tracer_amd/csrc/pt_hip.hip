@@ -637,10 +637,7 @@ __global__ void __launch_bounds__(64, MODE ? PT_GRID_WAVES_PER_EU : PT_WAVES_PER
 __device__ unsigned long long g_tprof[8192 * 4 + 8];
 #endif
 template <bool LDS>
-__global__ void __launch_bounds__(256)
-#ifdef PT_WAVEPROF
-__attribute__((amdgpu_waves_per_eu(6, 6)))      // the timing build keeps the occupancy of the product build (its extra registers would cost a wave)
-#endif
+__global__ void __launch_bounds__(256, LDS ? 6 : 5)   // six waves per SIMD with the scene in LDS: the launch is sized for them (render_core)
 k_tail(const RenderParams P) {
     constexpr int G = PT_TAIL_GROUP;
 #ifdef PT_WAVEPROF
