@@ -251,7 +251,14 @@ def measured_traffic(default_workload):
     if not default_workload:
         return None, None
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), reverse=True):
+    import re
+
+    def newest_first(path):
+        # r03_summary.json (the round's main collection) before r03c_, r03b_ (other boxes), before r02_ ...; the grid's are not these
+        m = re.match(r"r(\d+)([a-z]?)_summary\.json$", os.path.basename(path))
+        return (-int(m.group(1)), m.group(2)) if m else (1, path)
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=newest_first):
         try:
             with open(path) as f:
                 return float(json.load(f)["k_render_hbm_bytes_per_launch"]["total"]), os.path.relpath(path, ROOT)
