@@ -50,6 +50,10 @@ KERNEL_HEAD(k_sub_sv)    asm volatile("v_sub_f32 %0, %1, %0"     : "+v"(acc[i]) 
 KERNEL_HEAD(k_cmp_sv)    asm volatile("v_cmp_gt_f32 vcc, %1, %0" : "+v"(acc[i]) : "s"(a) : "vcc");   KERNEL_TAIL
 KERNEL_HEAD(k_pk_vvv)    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(acc2[i]) : "v"(va), "v"(vb)); KERNEL_TAIL
 KERNEL_HEAD(k_pk_svv)    asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(acc2[i]) : "s"(va), "v"(vb)); KERNEL_TAIL
+// the scan's own shape, acc = s * ray + acc, and the same with the ray operand splat from ONE register (op_sel_hi: both halves
+// take the low word): does reading fewer vector registers per instruction issue faster?
+KERNEL_HEAD(k_pk_sva)    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2[i]) : "s"(va), "v"(vb)); KERNEL_TAIL
+KERNEL_HEAD(k_pk_sva_splat) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[i]) : "s"(va), "v"(vb)); KERNEL_TAIL
 KERNEL_HEAD(k_pk_mul_sv) asm volatile("v_pk_mul_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
 KERNEL_HEAD(k_pk_add_sv) asm volatile("v_pk_add_f32 %0, %1, %0"  : "+v"(acc2[i]) : "s"(va));         KERNEL_TAIL
 // other instructions of the sample loop (issue cost only; operands are whatever the registers hold)
@@ -98,7 +102,7 @@ int main() {
     Form forms[] = {
         {"v_fma_f32 v,v,v", k_fma_vvv, 2}, {"v_fma_f32 s,v,v", k_fma_svv, 2}, {"v_fmac_f32 s,v", k_fmac_sv, 2},
         {"v_fmac_f32 v,v", k_fmac_vv, 2}, {"v_mul_f32 s,v", k_mul_sv, 1}, {"v_sub_f32 s,v", k_sub_sv, 1},
-        {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4},
+        {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4}, {"v_pk_fma_f32 s,v,acc", k_pk_sva, 4}, {"v_pk_fma_f32 s,v.lo splat,acc", k_pk_sva_splat, 4},
         {"v_pk_mul_f32 s,v", k_pk_mul_sv, 2}, {"v_pk_add_f32 s,v", k_pk_add_sv, 2},
         {"v_max_f32 v,v", k_max_vv, 1}, {"v_max3_f32 v,v,v", k_max3_vvv, 1}, {"v_cmp_ge_f32 v,v", k_cmp_vv, 1},
         {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32 sgpr mask", k_cndmask_s, 1}, {"v_xor_b32", k_xor, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1},
