@@ -90,6 +90,110 @@ KERNEL_HEAD(k_cvt_f64)   asm volatile("v_cvt_f64_f32 %0, %1"     : "+v"(acc2[i])
 KERNEL_HEAD(k_rsq_f64)   asm volatile("v_rsq_f64 %0, %0"         : "+v"(acc2[i]));                   KERNEL_TAIL
 
 typedef void (*kern_t)(float*, unsigned long long*, float, float);
+// Do the vector register banks matter for the scan's FMA shape, acc = s * ray + acc? Sixteen accumulator pairs at
+// v[0:1], v[4:5] ... (registers 0 and 1 modulo 4) and the ray operand either in a pair of the same residues (v[64:65]) or of
+// the other two (v[66:67]). Hard-coded registers: the allocator must not choose.
+#define BANK_KERNEL(name, MPAIR)                                                                                         \
+    __global__ void __launch_bounds__(256) name(float* out, unsigned long long* cyc, float a, float b) {                 \
+        float2v va = {a, a * 1.0001f};                                                                                   \
+        float r;                                                                                                         \
+        asm volatile("v_mov_b32 v64, %0\n\tv_mov_b32 v65, %0\n\tv_mov_b32 v66, %0\n\tv_mov_b32 v67, %0" :: "v"(b) : "v64", "v65", "v66", "v67"); \
+        asm volatile("v_mov_b32 v0, %0\n\tv_mov_b32 v1, %0\n\tv_mov_b32 v4, %0\n\tv_mov_b32 v5, %0\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %0\n\t" \
+                     "v_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\tv_mov_b32 v16, %0\n\tv_mov_b32 v17, %0\n\tv_mov_b32 v20, %0\n\tv_mov_b32 v21, %0\n\t" \
+                     "v_mov_b32 v24, %0\n\tv_mov_b32 v25, %0\n\tv_mov_b32 v28, %0\n\tv_mov_b32 v29, %0\n\tv_mov_b32 v32, %0\n\tv_mov_b32 v33, %0\n\t" \
+                     "v_mov_b32 v36, %0\n\tv_mov_b32 v37, %0\n\tv_mov_b32 v40, %0\n\tv_mov_b32 v41, %0\n\tv_mov_b32 v44, %0\n\tv_mov_b32 v45, %0\n\t" \
+                     "v_mov_b32 v48, %0\n\tv_mov_b32 v49, %0\n\tv_mov_b32 v52, %0\n\tv_mov_b32 v53, %0\n\tv_mov_b32 v56, %0\n\tv_mov_b32 v57, %0\n\t" \
+                     "v_mov_b32 v60, %0\n\tv_mov_b32 v61, %0" :: "v"(a) : BANK_CLOBBERS);                                  \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                            \
+        for (int it = 0; it < ITERS; ++it) {                                                                             \
+            asm volatile("v_pk_fma_f32 v[0:1], %0, " MPAIR ", v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, " MPAIR ", v[4:5]\n\t"  \
+                         "v_pk_fma_f32 v[8:9], %0, " MPAIR ", v[8:9]\n\tv_pk_fma_f32 v[12:13], %0, " MPAIR ", v[12:13]\n\t" \
+                         "v_pk_fma_f32 v[16:17], %0, " MPAIR ", v[16:17]\n\tv_pk_fma_f32 v[20:21], %0, " MPAIR ", v[20:21]\n\t" \
+                         "v_pk_fma_f32 v[24:25], %0, " MPAIR ", v[24:25]\n\tv_pk_fma_f32 v[28:29], %0, " MPAIR ", v[28:29]\n\t" \
+                         "v_pk_fma_f32 v[32:33], %0, " MPAIR ", v[32:33]\n\tv_pk_fma_f32 v[36:37], %0, " MPAIR ", v[36:37]\n\t" \
+                         "v_pk_fma_f32 v[40:41], %0, " MPAIR ", v[40:41]\n\tv_pk_fma_f32 v[44:45], %0, " MPAIR ", v[44:45]\n\t" \
+                         "v_pk_fma_f32 v[48:49], %0, " MPAIR ", v[48:49]\n\tv_pk_fma_f32 v[52:53], %0, " MPAIR ", v[52:53]\n\t" \
+                         "v_pk_fma_f32 v[56:57], %0, " MPAIR ", v[56:57]\n\tv_pk_fma_f32 v[60:61], %0, " MPAIR ", v[60:61]"     \
+                         :: "s"(va) : BANK_CLOBBERS);                                                                    \
+        }                                                                                                                \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                            \
+        asm volatile("v_add_f32 %0, v0, v61" : "=v"(r) :: BANK_CLOBBERS);                                                \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                                  \
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                 \
+    }
+#define BANK_CLOBBERS "v0", "v1", "v4", "v5", "v8", "v9", "v12", "v13", "v16", "v17", "v20", "v21", "v24", "v25", "v28", "v29", "v32", "v33", \
+                      "v36", "v37", "v40", "v41", "v44", "v45", "v48", "v49", "v52", "v53", "v56", "v57", "v60", "v61", "v64", "v65", "v66", "v67"
+BANK_KERNEL(k_bank_same, "v[64:65]")
+BANK_KERNEL(k_bank_other, "v[66:67]")
+// the same sixteen instructions on CONSECUTIVE accumulator pairs v[0:1], v[2:3] ... v[30:31] (what an allocator hands out)
+#define SEQ_CLOBBERS "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", \
+                     "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v64", "v65"
+__global__ void __launch_bounds__(256) k_bank_seq(float* out, unsigned long long* cyc, float a, float b) {
+    float2v va = {a, a * 1.0001f};
+    float r;
+    asm volatile("v_mov_b32 v64, %0\n\tv_mov_b32 v65, %0" :: "v"(b) : "v64", "v65");
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITERS; ++it) {
+        asm volatile("v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[2:3], %0, v[64:65], v[2:3]\n\t"
+                     "v_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\tv_pk_fma_f32 v[6:7], %0, v[64:65], v[6:7]\n\t"
+                     "v_pk_fma_f32 v[8:9], %0, v[64:65], v[8:9]\n\tv_pk_fma_f32 v[10:11], %0, v[64:65], v[10:11]\n\t"
+                     "v_pk_fma_f32 v[12:13], %0, v[64:65], v[12:13]\n\tv_pk_fma_f32 v[14:15], %0, v[64:65], v[14:15]\n\t"
+                     "v_pk_fma_f32 v[16:17], %0, v[64:65], v[16:17]\n\tv_pk_fma_f32 v[18:19], %0, v[64:65], v[18:19]\n\t"
+                     "v_pk_fma_f32 v[20:21], %0, v[64:65], v[20:21]\n\tv_pk_fma_f32 v[22:23], %0, v[64:65], v[22:23]\n\t"
+                     "v_pk_fma_f32 v[24:25], %0, v[64:65], v[24:25]\n\tv_pk_fma_f32 v[26:27], %0, v[64:65], v[26:27]\n\t"
+                     "v_pk_fma_f32 v[28:29], %0, v[64:65], v[28:29]\n\tv_pk_fma_f32 v[30:31], %0, v[64:65], v[30:31]"
+                     :: "s"(va) : SEQ_CLOBBERS);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("v_add_f32 %0, v0, v31" : "=v"(r) :: SEQ_CLOBBERS);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+// ... and with only FOUR accumulators (each instruction depends on the fourth before it, as in a chain-interleaved scan)
+__global__ void __launch_bounds__(256) k_bank_dep4(float* out, unsigned long long* cyc, float a, float b) {
+    float2v va = {a, a * 1.0001f};
+    float r;
+    asm volatile("v_mov_b32 v64, %0\n\tv_mov_b32 v65, %0" :: "v"(b) : "v64", "v65");
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITERS; ++it) {
+        asm volatile("v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[8:9], %0, v[64:65], v[8:9]\n\tv_pk_fma_f32 v[12:13], %0, v[64:65], v[12:13]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[8:9], %0, v[64:65], v[8:9]\n\tv_pk_fma_f32 v[12:13], %0, v[64:65], v[12:13]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[8:9], %0, v[64:65], v[8:9]\n\tv_pk_fma_f32 v[12:13], %0, v[64:65], v[12:13]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[8:9], %0, v[64:65], v[8:9]\n\tv_pk_fma_f32 v[12:13], %0, v[64:65], v[12:13]"
+                     :: "s"(va) : SEQ_CLOBBERS);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("v_add_f32 %0, v0, v13" : "=v"(r) :: SEQ_CLOBBERS);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+// ... and with TWO (each depends on the second before it: the scan's two chains)
+__global__ void __launch_bounds__(256) k_bank_dep2(float* out, unsigned long long* cyc, float a, float b) {
+    float2v va = {a, a * 1.0001f};
+    float r;
+    asm volatile("v_mov_b32 v64, %0\n\tv_mov_b32 v65, %0" :: "v"(b) : "v64", "v65");
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITERS; ++it) {
+        asm volatile("v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]\n\t"
+                     "v_pk_fma_f32 v[0:1], %0, v[64:65], v[0:1]\n\tv_pk_fma_f32 v[4:5], %0, v[64:65], v[4:5]"
+                     :: "s"(va) : SEQ_CLOBBERS);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("v_add_f32 %0, v0, v5" : "=v"(r) :: SEQ_CLOBBERS);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 struct Form { const char* name; kern_t k; int flops_per_lane; };
 
 int main() {
@@ -103,6 +207,8 @@ int main() {
         {"v_fma_f32 v,v,v", k_fma_vvv, 2}, {"v_fma_f32 s,v,v", k_fma_svv, 2}, {"v_fmac_f32 s,v", k_fmac_sv, 2},
         {"v_fmac_f32 v,v", k_fmac_vv, 2}, {"v_mul_f32 s,v", k_mul_sv, 1}, {"v_sub_f32 s,v", k_sub_sv, 1},
         {"v_cmp_gt_f32 s,v", k_cmp_sv, 1}, {"v_pk_fma_f32 v,v,v", k_pk_vvv, 4}, {"v_pk_fma_f32 s,v,v", k_pk_svv, 4}, {"v_pk_fma_f32 s,v,acc", k_pk_sva, 4}, {"v_pk_fma_f32 s,v.lo splat,acc", k_pk_sva_splat, 4},
+        {"pk_fma s,v,acc same banks", k_bank_same, 4}, {"pk_fma s,v,acc other banks", k_bank_other, 4},
+        {"pk_fma s,v,acc consecutive pairs", k_bank_seq, 4}, {"pk_fma s,v,acc 4 chains", k_bank_dep4, 4}, {"pk_fma s,v,acc 2 chains", k_bank_dep2, 4},
         {"v_pk_mul_f32 s,v", k_pk_mul_sv, 2}, {"v_pk_add_f32 s,v", k_pk_add_sv, 2},
         {"v_max_f32 v,v", k_max_vv, 1}, {"v_max3_f32 v,v,v", k_max3_vvv, 1}, {"v_cmp_ge_f32 v,v", k_cmp_vv, 1},
         {"v_cndmask_b32", k_cndmask, 1}, {"v_cndmask_b32 sgpr mask", k_cndmask_s, 1}, {"v_xor_b32", k_xor, 1}, {"v_sqrt_f32", k_sqrt, 1}, {"v_rsq_f32", k_rsq, 1},
