@@ -13,7 +13,8 @@ WANT = {                                  # kernel (mangled prefix) -> fewest wa
     "_Z8k_renderILi0E": 6,
     "_Z8k_renderILi1E": 5,
     "_Z8k_renderILi2E": 5,
-    "_Z6k_tailILb": 4,
+    "_Z6k_tailILb1E": 6,                  # k_tail<true>: render_core sizes its launch for six waves per SIMD (scene copies in LDS)
+    "_Z6k_tailILb0E": 5,
 }
 
 
